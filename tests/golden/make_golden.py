@@ -1,0 +1,75 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python oracle.
+
+Run in the build container only (needs /root/reference; the GPU box has none):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What runs: ``ms_deform_attn_core_pytorch`` (reference
+mask2former/modeling/pixel_decoder/ops/functions/ms_deform_attn_func.py:52-72)
+in float64 on the seeded inputs of cases.py, with float64 autograd for the three
+gradients, and -- for the module fixture -- the reference ``MSDeformAttn``
+module (ops/modules/ms_deform_attn.py:34-125) on CPU, which reaches the same
+function through its bare ``except`` (:119-121).  The reference imports a
+compiled extension at module scope (ms_deform_attn_func.py:21-29); an empty
+stand-in module of that name is registered first so the import succeeds -- the
+extension itself is never called on this path.
+
+Only the OUTPUTS are stored; inputs are re-created from cases.py's seeds.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+REF_OPS_PARENT = "/root/reference/mask2former/modeling/pixel_decoder"
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("MultiScaleDeformableAttention",
+                           types.ModuleType("MultiScaleDeformableAttention"))
+    sys.path.insert(0, REF_OPS_PARENT)
+    from ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    from ops.modules.ms_deform_attn import MSDeformAttn
+    return ms_deform_attn_core_pytorch, MSDeformAttn
+
+
+def main():
+    core, MSDeformAttn = import_reference()
+    torch.set_num_threads(4)
+    for name in cases.CASES:
+        c = cases.make_case(name)
+        value = torch.from_numpy(c["value"]).requires_grad_(True)
+        loc = torch.from_numpy(c["loc"]).requires_grad_(True)
+        aw = torch.from_numpy(c["aw"]).requires_grad_(True)
+        shapes = torch.from_numpy(c["shapes"])
+        out = core(value, shapes, loc, aw)
+        out.backward(torch.from_numpy(c["grad_out"]))
+        path = os.path.join(HERE, name + ".npz")
+        np.savez(path, out=out.detach().numpy(), grad_value=value.grad.numpy(),
+                 grad_loc=loc.grad.numpy(), grad_aw=aw.grad.numpy())
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+    mc = cases.make_module_case()
+    mod = MSDeformAttn(d_model=mc["d_model"], n_levels=mc["n_levels"],
+                       n_heads=mc["n_heads"], n_points=mc["n_points"]).double()
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in mc["state_dict"].items()})
+    query = torch.from_numpy(mc["query"]).requires_grad_(True)
+    src = torch.from_numpy(mc["src"]).requires_grad_(True)
+    out = mod(query, torch.from_numpy(mc["ref"]), src, torch.from_numpy(mc["shapes"]),
+              torch.from_numpy(mc["lsi"]), torch.from_numpy(mc["padding_mask"]))
+    g = torch.from_numpy(np.random.RandomState(202).standard_normal(tuple(out.shape)).astype(np.float32)).double()
+    out.backward(g)
+    path = os.path.join(HERE, "module_msdeformattn.npz")
+    np.savez(path, out=out.detach().numpy(), grad_query=query.grad.numpy(), grad_src=src.grad.numpy())
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

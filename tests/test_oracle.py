@@ -1,0 +1,61 @@
+"""CPU: pins the oracle (C restatement and torch restatement) to the golden
+vectors produced by the reference's own ms_deform_attn_core_pytorch + fp64
+autograd (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import load_golden, rel_err
+from oracle import msda_torch
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_c_oracle_f64_matches_reference(oracle, name):
+    c, g = cases.make_case(name), load_golden(name)
+    out = oracle.forward(c["value"], c["shapes"], c["lsi"], c["loc"], c["aw"])
+    gv, gl, ga = oracle.backward(c["value"], c["shapes"], c["lsi"], c["loc"], c["aw"], c["grad_out"])
+    # the reference's own fp64 forward check uses allclose defaults (ops/test.py:43)
+    assert np.allclose(out, g["out"], rtol=1e-5, atol=1e-8)
+    assert rel_err(out, g["out"]) < 1e-12
+    assert rel_err(gv, g["grad_value"]) < 1e-12
+    assert rel_err(gl, g["grad_loc"]) < 1e-11
+    assert rel_err(ga, g["grad_aw"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_c_oracle_f32_matches_reference(oracle, name):
+    c, g = cases.make_case(name), load_golden(name)
+    f = lambda k: c[k].astype(np.float32)
+    out = oracle.forward(f("value"), c["shapes"], c["lsi"], f("loc"), f("aw"))
+    gv, gl, ga = oracle.backward(f("value"), c["shapes"], c["lsi"], f("loc"), f("aw"), f("grad_out"))
+    assert out.dtype == np.float32
+    assert rel_err(out, g["out"]) < 1e-5          # north-star forward bar
+    assert rel_err(gv, g["grad_value"]) < 1e-4    # north-star gradient bar
+    assert rel_err(gl, g["grad_loc"]) < 1e-4
+    assert rel_err(ga, g["grad_aw"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_torch_restatement_matches_reference(name):
+    c, g = cases.make_case(name), load_golden(name)
+    t = lambda k: torch.from_numpy(c[k])
+    out, gv, gl, ga = msda_torch.msda_forward_backward_torch(
+        t("value"), c["shapes"], t("loc"), t("aw"), t("grad_out"))
+    assert rel_err(out.numpy(), g["out"]) < 1e-12
+    assert rel_err(gv.numpy(), g["grad_value"]) < 1e-12
+    assert rel_err(gl.numpy(), g["grad_loc"]) < 1e-11
+    assert rel_err(ga.numpy(), g["grad_aw"]) < 1e-12
+
+
+def test_oracle_thread_count_independent(oracle):
+    """OpenMP partitioning is over (n, m): results must not depend on threads."""
+    import os
+    c = cases.make_case("batch4")
+    a = oracle.backward(c["value"], c["shapes"], c["lsi"], c["loc"], c["aw"], c["grad_out"])
+    old = os.environ.get("OMP_NUM_THREADS")
+    b = oracle.backward(c["value"], c["shapes"], c["lsi"], c["loc"], c["aw"], c["grad_out"])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    if old is not None:
+        os.environ["OMP_NUM_THREADS"] = old
