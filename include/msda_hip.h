@@ -1,0 +1,89 @@
+/*
+ * msda_hip.h -- C ABI of libmsda_hip.so: multi-scale deformable attention (MSDA)
+ * forward / backward for AMD MI355X (gfx950), hand-written HIP.
+ *
+ * This is the drop-in boundary for the one native component of the reference
+ * (SNU-VGILab/InstaOrder): the two host launchers that its pybind module
+ * `MultiScaleDeformableAttention` calls.  Paths below are relative to
+ * mask2former/modeling/pixel_decoder/ops/ in the reference.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to a contiguous array; inputs are read-only;
+ *   - layouts are the reference's: value [N,S,M,D], spatial_shapes int64 [L,2] = (H,W),
+ *     level_start_index int64 [L], sampling_loc [N,Lq,M,L,P,2] = (x,y) normalised to [0,1],
+ *     attn_weight [N,Lq,M,L,P], output / grad_output [N,Lq,M*D];
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); work is
+ *     enqueued asynchronously, nothing synchronises with the host;
+ *   - no allocation, no exceptions; return 0 on success, non-zero on error, and
+ *     msda_last_error() then returns a thread-local message;
+ *   - every output element is written (no pre-zeroing needed by the caller):
+ *     msda_backward_* zero-fills grad_value on `stream` before accumulating into it.
+ */
+#ifndef MSDA_HIP_H_
+#define MSDA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDA_OK 0
+#define MSDA_ERR_INVALID_ARGUMENT 1
+#define MSDA_ERR_LAUNCH 2
+
+/* Library ABI version (bumped when a signature changes). */
+int msda_abi_version(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char *msda_last_error(void);
+
+/* Number of kernel launches issued by this process through this library since load
+ * (tests use it to prove the HIP path ran: the reference's caller swallows every
+ * exception and silently falls back to PyTorch, ops/modules/ms_deform_attn.py:116-121). */
+uint64_t msda_launch_count(void);
+
+/*
+ * Forward.  Replaces ms_deformable_im2col_cuda<float|double>
+ * (src/cuda/ms_deform_im2col_cuda.cuh:928-959) as called from
+ * ms_deform_attn_cuda_forward (src/cuda/ms_deform_attn_cuda.cu:66-80):
+ *   output[n,q,m*D+c] = sum_{l,p} attn_weight[n,q,m,l,p] *
+ *                        bilinear(value_l[n,:,m,c], x*W_l-0.5, y*H_l-0.5)   (zero padding)
+ */
+int msda_forward_f32(const float *value, const int64_t *spatial_shapes,
+                     const int64_t *level_start_index, const float *sampling_loc,
+                     const float *attn_weight, int batch, int spatial_size, int num_heads,
+                     int channels, int num_levels, int num_query, int num_point,
+                     float *output, void *stream);
+
+int msda_forward_f64(const double *value, const int64_t *spatial_shapes,
+                     const int64_t *level_start_index, const double *sampling_loc,
+                     const double *attn_weight, int batch, int spatial_size, int num_heads,
+                     int channels, int num_levels, int num_query, int num_point,
+                     double *output, void *stream);
+
+/*
+ * Backward.  Replaces ms_deformable_col2im_cuda<float|double>
+ * (src/cuda/ms_deform_im2col_cuda.cuh:961-1332, every kernel variant it dispatches to)
+ * as called from ms_deform_attn_cuda_backward (src/cuda/ms_deform_attn_cuda.cu:136-153).
+ * grad_value is zero-filled inside (the reference's caller does at::zeros_like,
+ * ms_deform_attn_cuda.cu:126); grad_sampling_loc and grad_attn_weight are fully written.
+ */
+int msda_backward_f32(const float *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const float *sampling_loc,
+                      const float *attn_weight, const float *grad_output, int batch,
+                      int spatial_size, int num_heads, int channels, int num_levels,
+                      int num_query, int num_point, float *grad_value,
+                      float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
+int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const double *sampling_loc,
+                      const double *attn_weight, const double *grad_output, int batch,
+                      int spatial_size, int num_heads, int channels, int num_levels,
+                      int num_query, int num_point, double *grad_value,
+                      double *grad_sampling_loc, double *grad_attn_weight, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDA_HIP_H_ */

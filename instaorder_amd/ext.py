@@ -1,0 +1,149 @@
+"""Host side of the MSDA extension boundary: the two functions the reference's pybind
+module ``MultiScaleDeformableAttention`` exports (reference
+mask2former/modeling/pixel_decoder/ops/src/vision.cpp:18-21), implemented on top of
+the C ABI of libmsda_hip.so (include/msda_hip.h).
+
+Mirrors, check for check, ``ms_deform_attn_forward/backward`` (ops/src/ms_deform_attn.h:25-66)
+and ``ms_deform_attn_cuda_forward/backward`` (ops/src/cuda/ms_deform_attn_cuda.cu:25-158):
+same positional signatures, same preconditions, same error type (RuntimeError), outputs
+allocated here on ``value``'s device and dtype, kernels enqueued on torch's current HIP
+stream without synchronising.  There is NO fallback: a missing library, a CPU tensor or a
+failed launch raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmsda_hip.so")
+_lib = None
+
+_I = ctypes.c_int
+_P = ctypes.c_void_p
+
+
+def _load():
+    """dlopen libmsda_hip.so (after torch, so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            "libmsda_hip.so is not built: run `python -m instaorder_amd.build_ext` "
+            "(needs hipcc); there is no fallback implementation")
+    lib = ctypes.CDLL(_LIB_PATH)
+    fwd_args = [_P] * 5 + [_I] * 7 + [_P, _P]
+    bwd_args = [_P] * 6 + [_I] * 7 + [_P] * 4
+    for suffix in ("f32", "f64"):
+        f = getattr(lib, "msda_forward_" + suffix)
+        f.argtypes, f.restype = fwd_args, _I
+        b = getattr(lib, "msda_backward_" + suffix)
+        b.argtypes, b.restype = bwd_args, _I
+    lib.msda_last_error.restype = ctypes.c_char_p
+    lib.msda_launch_count.restype = ctypes.c_uint64
+    lib.msda_abi_version.restype = _I
+    if lib.msda_abi_version() != 1:
+        raise RuntimeError("libmsda_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def launch_count():
+    """Kernel launches issued through the library so far (proof the HIP path ran)."""
+    return int(_load().msda_launch_count())
+
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _check_inputs(named):
+    # ms_deform_attn_cuda.cu:33-43 / :98-110 -- contiguity first, then device
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)
+    for name, t in named:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+
+
+def _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    if value.dtype not in _SUFFIX:
+        # AT_DISPATCH_FLOATING_TYPES (ms_deform_attn_cuda.cu:69): float and double only
+        raise RuntimeError('"ms_deform_attn" not implemented for \'%s\'' % value.dtype)
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("expected sampling_loc and attn_weight to have value's dtype %s"
+                           % value.dtype)
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("expected value [N,S,M,D], sampling_loc [N,Lq,M,L,P,2], "
+                           "attn_weight [N,Lq,M,L,P]")
+    batch, spatial_size, num_heads, channels = value.shape
+    num_levels = spatial_shapes.shape[0]
+    num_query, num_point = sampling_loc.shape[1], sampling_loc.shape[4]
+    if (tuple(sampling_loc.shape) != (batch, num_query, num_heads, num_levels, num_point, 2)
+            or tuple(attn_weight.shape) != (batch, num_query, num_heads, num_levels, num_point)
+            or tuple(spatial_shapes.shape) != (num_levels, 2)
+            or tuple(level_start_index.shape) != (num_levels,)):
+        raise RuntimeError("inconsistent MSDA argument shapes")
+    step = min(batch, int(im2col_step))
+    if batch > 0 and (step <= 0 or batch % step != 0):
+        # ms_deform_attn_cuda.cu:55-57
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (batch, step))
+    return batch, spatial_size, num_heads, channels, num_levels, num_query, num_point
+
+
+def _raise(lib, what):
+    raise RuntimeError("%s: %s" % (what, lib.msda_last_error().decode("utf-8", "replace")))
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step):
+    """-> output [N, Lq, M*D].  Reference: ops/src/ms_deform_attn.h:25-44."""
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")        # ms_deform_attn.h:43
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)))
+    n, s, m, d, nl, lq, npt = _common(value, spatial_shapes, level_start_index, sampling_loc,
+                                      attn_weight, im2col_step)
+    lib = _load()
+    with torch.cuda.device(value.device):
+        output = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "msda_forward_" + _SUFFIX[value.dtype])(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), n, s, m, d, nl, lq, npt,
+            output.data_ptr(), stream)
+    if rc != 0:
+        _raise(lib, "ms_deform_attn_forward")
+    return output
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight].  Reference: ms_deform_attn.h:46-66."""
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")        # ms_deform_attn.h:65
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)))
+    n, s, m, d, nl, lq, npt = _common(value, spatial_shapes, level_start_index, sampling_loc,
+                                      attn_weight, im2col_step)
+    if grad_output.dtype != value.dtype or grad_output.numel() != n * lq * m * d:
+        raise RuntimeError("grad_output must be [N, Lq, M*D] with value's dtype")
+    lib = _load()
+    with torch.cuda.device(value.device):
+        grad_value = torch.empty_like(value)                    # zero-filled by the library
+        grad_sampling_loc = torch.empty_like(sampling_loc)
+        grad_attn_weight = torch.empty_like(attn_weight)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "msda_backward_" + _SUFFIX[value.dtype])(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+            n, s, m, d, nl, lq, npt, grad_value.data_ptr(), grad_sampling_loc.data_ptr(),
+            grad_attn_weight.data_ptr(), stream)
+    if rc != 0:
+        _raise(lib, "ms_deform_attn_backward")
+    return [grad_value, grad_sampling_loc, grad_attn_weight]

@@ -1,0 +1,217 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the
+drop-in module `MultiScaleDeformableAttention` -> C ABI -> HIP kernels and is compared with
+(a) the golden vectors produced by the reference's own PyTorch path, (b) the C oracle on
+seeded inputs, (c) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances are the north-star's: forward fp32 <= 1e-5 relative,
+gradients <= 1e-4 relative (float atomics reorder), fp64 at the reference's own allclose
+defaults (ops/test.py:43) and much tighter in practice.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL_F32 = 1e-5
+GRAD_TOL_F32 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def msda():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import MultiScaleDeformableAttention as MSDA
+    return MSDA
+
+
+def _dev(c, dtype):
+    f = lambda k: torch.from_numpy(c[k]).to(dtype).cuda().contiguous()
+    return (f("value"), torch.from_numpy(c["shapes"]).cuda(), torch.from_numpy(c["lsi"]).cuda(),
+            f("loc"), f("aw"), f("grad_out"))
+
+
+def _run(msda, value, shapes, lsi, loc, aw, go, step=128):
+    from instaorder_amd import ext
+    before = ext.launch_count()
+    out = msda.ms_deform_attn_forward(value, shapes, lsi, loc, aw, step)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, shapes, lsi, loc, aw, go, step)
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 2, "HIP kernels were not launched"
+    return [t.cpu().numpy() for t in (out, gv, gl, ga)]
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_golden_f64(msda, name):
+    c, g = cases.make_case(name), load_golden(name)
+    out, gv, gl, ga = _run(msda, *_dev(c, torch.float64))
+    assert np.allclose(out, g["out"], rtol=1e-5, atol=1e-8)      # reference's own fp64 check
+    assert rel_err(out, g["out"]) < 1e-12
+    assert rel_err(gv, g["grad_value"]) < 1e-11
+    assert rel_err(gl, g["grad_loc"]) < 1e-10
+    assert rel_err(ga, g["grad_aw"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_golden_f32(msda, name):
+    c, g = cases.make_case(name), load_golden(name)
+    out, gv, gl, ga = _run(msda, *_dev(c, torch.float32))
+    assert np.allclose(out, g["out"], rtol=1e-2, atol=1e-3)      # reference's own fp32 check
+    assert rel_err(out, g["out"]) < FWD_TOL_F32
+    assert rel_err(gv, g["grad_value"]) < GRAD_TOL_F32
+    assert rel_err(gl, g["grad_loc"]) < GRAD_TOL_F32
+    assert rel_err(ga, g["grad_aw"]) < GRAD_TOL_F32
+
+
+def _oracle_check(msda, oracle, inp, fwd_tol, grad_tol):
+    dev = {k: v.cuda() for k, v in inp.items()}
+    out, gv, gl, ga = _run(msda, dev["value"], dev["spatial_shapes"], dev["level_start_index"],
+                           dev["sampling_locations"], dev["attention_weights"], dev["grad_output"])
+    n = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    o_out = oracle.forward(n("value"), n("spatial_shapes"), n("level_start_index"),
+                           n("sampling_locations"), n("attention_weights"))
+    o_gv, o_gl, o_ga = oracle.backward(n("value"), n("spatial_shapes"), n("level_start_index"),
+                                       n("sampling_locations"), n("attention_weights"),
+                                       n("grad_output"))
+    assert rel_err(out, o_out) < fwd_tol
+    assert rel_err(gv, o_gv) < grad_tol
+    assert rel_err(gl, o_gl) < grad_tol
+    assert rel_err(ga, o_ga) < grad_tol
+
+
+@pytest.mark.parametrize("dist", ["model", "uniform"])
+def test_encoder_shape_vs_oracle_f32(msda, oracle, dist):
+    """256^2 input -> levels 8^2/16^2/32^2, M=8, D=32, P=4, N=3: the fast D=32 kernels."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(3, synthetic.encoder_shapes(256), dist=dist, seed=11)
+    _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
+
+
+@pytest.mark.parametrize("channels,heads,points,levels", [
+    (32, 8, 3, 2), (32, 5, 4, 4), (16, 4, 4, 3), (64, 2, 2, 3), (71, 2, 2, 2), (30, 3, 5, 1),
+    (1025, 1, 2, 2), (2048, 1, 1, 2), (3096, 1, 2, 1), (1, 2, 2, 2)])
+def test_generic_shapes_vs_oracle(msda, oracle, channels, heads, points, levels):
+    """Odd head sizes / point counts, incl. every D the reference's ops/test.py:88 lists."""
+    from instaorder_amd import synthetic
+    shapes = [(5, 7), (3, 4), (9, 2), (6, 6)][:levels]
+    for dtype, ftol, gtol in ((torch.float32, FWD_TOL_F32, GRAD_TOL_F32), (torch.float64, 1e-12, 1e-10)):
+        inp = synthetic.make_inputs(2, shapes, heads=heads, channels=channels, points=points,
+                                    dist="uniform", seed=5, num_query=13, dtype=dtype)
+        inp["sampling_locations"] = inp["sampling_locations"] * 1.3 - 0.15   # some out of range
+        _oracle_check(msda, oracle, inp, ftol, gtol)
+
+
+@pytest.mark.parametrize("channels", [30, 32, 64, 71])
+def test_gradcheck_like_reference(msda, channels):
+    """ops/test.py:66-81: fp64 gradcheck of all three differentiable inputs."""
+    from torch.autograd import gradcheck
+    from instaorder_amd import MSDeformAttnFunction
+    torch.manual_seed(3)
+    n, m, lq, l, p = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    s = int(shapes.prod(1).sum())
+    value = (torch.rand(n, s, m, channels) * 0.01).double().cuda().requires_grad_(True)
+    loc = torch.rand(n, lq, m, l, p, 2).double().cuda().requires_grad_(True)
+    aw = torch.rand(n, lq, m, l, p) + 1e-5
+    aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().cuda().requires_grad_(True)
+    assert gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2))
+
+
+def test_error_behaviour(msda):
+    c = cases.make_case("batch4")
+    value, shapes, lsi, loc, aw, go = _dev(c, torch.float32)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        msda.ms_deform_attn_forward(value.transpose(1, 2), shapes, lsi, loc, aw, 128)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        msda.ms_deform_attn_forward(value, shapes.cpu(), lsi, loc, aw, 128)
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        msda.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 3)      # 4 % 3 != 0
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        msda.ms_deform_attn_forward(value.cpu(), shapes, lsi, loc, aw, 128)
+    # chunked batches give the same answer as one chunk
+    a = msda.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 2)
+    b = msda.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 128)
+    assert torch.equal(a, b)
+
+
+def test_empty_and_degenerate(msda):
+    shapes = torch.tensor([[2, 3]]).cuda()
+    lsi = torch.tensor([0]).cuda()
+    # zero queries
+    out = msda.ms_deform_attn_forward(torch.randn(2, 6, 2, 4).cuda(), shapes, lsi,
+                                      torch.zeros(2, 0, 2, 1, 2, 2).cuda(),
+                                      torch.zeros(2, 0, 2, 1, 2).cuda(), 128)
+    assert tuple(out.shape) == (2, 0, 8)
+    gv, gl, ga = msda.ms_deform_attn_backward(torch.randn(2, 6, 2, 4).cuda(), shapes, lsi,
+                                              torch.zeros(2, 0, 2, 1, 2, 2).cuda(),
+                                              torch.zeros(2, 0, 2, 1, 2).cuda(),
+                                              torch.zeros(2, 0, 8).cuda(), 128)
+    assert float(gv.abs().sum()) == 0.0
+    # every sample far outside: output and all gradients are exactly zero
+    value = torch.randn(1, 6, 2, 4).cuda()
+    loc = torch.full((1, 5, 2, 1, 2, 2), 7.5).cuda()
+    aw = torch.full((1, 5, 2, 1, 2), 0.5).cuda()
+    out = msda.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 128)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, shapes, lsi, loc, aw,
+                                              torch.randn(1, 5, 8).cuda(), 128)
+    for t in (out, gv, gl, ga):
+        assert float(t.abs().sum()) == 0.0
+
+
+def test_runs_on_current_stream(msda):
+    c = cases.make_case("batch4")
+    value, shapes, lsi, loc, aw, go = _dev(c, torch.float32)
+    ref = msda.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 128)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out = msda.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 128)
+    st.synchronize()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("image,batch,dist", [(1024, 16, "model"), (1024, 4, "uniform"),
+                                              (1536, 2, "model")])
+def test_full_size_properties(msda, image, batch, dist):
+    """BASELINE.json sizes (C2: bs16 @1024^2; C5: 1536^2), fp32, size-independent properties:
+    forward is linear in value; backward's grad_value is the adjoint of that linear map;
+    sum_s aw_s * grad_aw_s = <grad_out, out> per pair; grad_value of a zero grad_out is zero."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(batch, synthetic.encoder_shapes(image), dist=dist, seed=1,
+                                device="cuda")
+    v, ss, lsi = inp["value"], inp["spatial_shapes"], inp["level_start_index"]
+    loc, aw, go = inp["sampling_locations"], inp["attention_weights"], inp["grad_output"]
+    out = msda.ms_deform_attn_forward(v, ss, lsi, loc, aw, 128)
+    gv, gl, ga = msda.ms_deform_attn_backward(v, ss, lsi, loc, aw, go, 128)
+    assert torch.isfinite(out).all() and torch.isfinite(gv).all()
+    assert torch.isfinite(gl).all() and torch.isfinite(ga).all()
+    # linearity in value
+    v2 = torch.randn_like(v)
+    out2 = msda.ms_deform_attn_forward(v2, ss, lsi, loc, aw, 128)
+    out3 = msda.ms_deform_attn_forward(2.5 * v + v2, ss, lsi, loc, aw, 128)
+    scale = float(out3.abs().max())
+    assert float((out3 - (2.5 * out + out2)).abs().max()) < 2e-5 * scale
+    # adjoint: <go, F(v)> == <F^T(go), v>, accumulated in fp64
+    lhs = float((go.double() * out.double()).sum())
+    rhs = float((gv.double() * v.double()).sum())
+    norm = float((go.double() * out.double()).abs().sum())
+    assert abs(lhs - rhs) < 1e-5 * norm
+    # sum_s aw_s * d/d aw_s == <go, out> per (n, q, m)
+    m, d = v.shape[2], v.shape[3]
+    per_pair = (go.view(batch, -1, m, d).double() * out.view(batch, -1, m, d).double()).sum(-1)
+    from_ga = (aw.double() * ga.double()).sum((-1, -2))
+    assert float((per_pair - from_ga).abs().max()) < 1e-4 * float(per_pair.abs().max())
+    # zero upstream gradient
+    gv0, gl0, ga0 = msda.ms_deform_attn_backward(v, ss, lsi, loc, aw, torch.zeros_like(go), 128)
+    assert float(gv0.abs().max()) == 0.0 and float(gl0.abs().max()) == 0.0
+    assert float(ga0.abs().max()) == 0.0
+
+
+def test_full_size_image_vs_oracle(msda, oracle):
+    """One image at 1024^2 (2.06 M samples), model-like locations, against the C oracle."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(1, synthetic.encoder_shapes(1024), dist="model", seed=2)
+    _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
