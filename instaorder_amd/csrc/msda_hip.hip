@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -53,16 +54,25 @@ template <typename T>
 struct Corner4 {
   T k1, k2, k3, k4;     // hh*hw, hh*lw, lh*hw, lh*lw, already 0 for out-of-level corners
   T lh, lw, hh, hw;
+  T h_im, w_im;         // pixel coordinates of the sample (loc * size - 0.5)
+  int h0, w0;           // top-left corner (floor of the above; 0 when the gate is closed)
   int o1, o2, o3, o4;   // pixel index (h*W + w) of each corner, clamped into the level
   bool ok1, ok2, ok3, ok4, in;
 };
+
+// loc * size - 0.5 as ONE fused multiply-add, so that every kernel (and both passes of the
+// tiled backward, which must agree on where a sample lands) gets bit-identical coordinates.
+__device__ __forceinline__ float pix_coord(float loc, float size) { return __fmaf_rn(loc, size, -0.5f); }
+__device__ __forceinline__ double pix_coord(double loc, double size) { return fma(loc, size, -0.5); }
 
 template <typename T>
 __device__ __forceinline__ Corner4<T> corner_setup(T lx, T ly, int H, int W) {
   Corner4<T> c;
   const T fH = (T)H, fW = (T)W;
-  const T h_im = ly * fH - (T)0.5;
-  const T w_im = lx * fW - (T)0.5;
+  const T h_im = pix_coord(ly, fH);
+  const T w_im = pix_coord(lx, fW);
+  c.h_im = h_im;
+  c.w_im = w_im;
   c.in = (h_im > (T)-1) && (w_im > (T)-1) && (h_im < fH) && (w_im < fW);
   // Outside the gate (or NaN) every weight is zero; park the coordinates at 0 so the
   // float->int conversion below is always defined.
@@ -73,6 +83,8 @@ __device__ __forceinline__ Corner4<T> corner_setup(T lx, T ly, int H, int W) {
   c.hh = (T)1 - c.lh;
   c.hw = (T)1 - c.lw;
   const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
+  c.h0 = h0;
+  c.w0 = w0;
   const bool h0ok = h0 >= 0, w0ok = w0 >= 0, h1ok = h1 <= H - 1, w1ok = w1 <= W - 1;
   c.ok1 = c.in && h0ok && w0ok;
   c.ok2 = c.in && h0ok && w1ok;
@@ -291,6 +303,451 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
   }
 }
 
+// =======================================================================================
+// Backward, fp32, D == 32, P == 4, encoder self-attention (Lq == S): destination-tiled.
+//
+// Why: scattering grad_value with global float atomics runs at the chip-wide atomic rate
+// (~1.35 TB/s measured: 12 ms for bs16 @1024^2), and LDS float atomics are no way out
+// (ds_add_f32 measured at ~185 cycles per wave-instruction on gfx950,
+// tools/microbench_lds_atomic.hip).  So grad_value is accumulated in REGISTERS, with no
+// float atomic anywhere on the common path:
+//
+//   * A work item is one (image n, head m, level l, 16x16-pixel tile of that level).  Its
+//     workgroup owns those 256 grad_value rows: thread (pixel, half) keeps 16 channels of
+//     one pixel in registers for the whole item and stores them once at the end (plain,
+//     coalesced stores; grad_value needs no zero-fill).
+//   * In encoder self-attention query q sits at a pixel centre of one of the levels, and
+//     samples land near that point.  The workgroup examines every *candidate* sample --
+//     queries of any level whose nominal centre, mapped into level l, lies within NEAR_R+1
+//     pixels of the tile -- one sample per thread, in chunks of 128 queries x 4 points.
+//     A sample is *near* if it lands within NEAR_R pixels of its query's nominal centre; a
+//     near sample touching the tile is therefore always among the tile's candidates.
+//   * Per chunk: counting sort of the (corner -> pixel) contributions in LDS (integer LDS
+//     atomics only), grad_output rows of the queries that hit staged once in LDS, then
+//     every pixel's owner threads walk their pixel's list: acc += w * grad_output_row.
+//   * The tile that holds a near sample's top-left corner (its *home*) also computes that
+//     sample's grad_sampling_loc / grad_attn_weight: 8 lanes x 4 channels read the four
+//     corner rows from an LDS copy of the (T+1)^2 value tile and the staged grad_output row.
+//   * Samples whose gate is closed get their zero gradients from the tile holding their
+//     query's nominal centre.  Samples that are in range but NOT near (none for model-like
+//     inputs) are left to msda_bwd_far_kernel, which runs afterwards on the same stream and
+//     adds them with global atomics -- correctness never depends on where samples land.
+//
+// Replaces ms_deformable_col2im_gpu_kernel_shm_blocksize_aware_reduce_v1<float, 32>
+// (ms_deform_im2col_cuda.cuh:306-408), the variant every InstaFormer config dispatches to.
+// =======================================================================================
+namespace tiled {
+
+constexpr int T = 16;             // tile side, pixels of the sampled level
+constexpr int TP = T * T;         // pixels per tile
+constexpr int VT = T + 1;         // value tile side (a home sample reaches one pixel further)
+constexpr int ZROW = VT * VT;     // all-zero row standing in for out-of-level corners
+constexpr int NT = 512;           // threads per workgroup (2 workgroups per CU by LDS)
+constexpr int P = 4;              // points per level on this path
+constexpr int CQ = NT / P;        // candidate queries per chunk: one sample per thread
+constexpr int MAXL = 8;
+constexpr float NEAR_R = 6.0f;    // pixels; see the near/far contract above
+
+// Nominal centre of query pixel `xq` (level of width Wq) in the coordinates of the sampled
+// level, given scale = W / Wq.  Explicitly rounded steps: both kernels must agree exactly.
+__device__ __forceinline__ float nominal_centre(int xq, float scale) {
+  return __fsub_rn(__fmul_rn((float)xq + 0.5f, scale), 0.5f);
+}
+__device__ __forceinline__ float level_scale(int W, int Wq) { return __fdiv_rn((float)W, (float)Wq); }
+
+__device__ __forceinline__ bool is_near(const Corner4<float> &g, float cx, float cy) {
+  return g.in && fabsf(g.w_im - cx) <= NEAR_R && fabsf(g.h_im - cy) <= NEAR_R;
+}
+
+__global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int L,
+    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
+  __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile, 16-B chunks XOR-swizzled by row
+  __shared__ float4 s_go[CQ * 8];           // grad_output rows of this chunk's queries (swizzled)
+  __shared__ uint2 s_rec[NT * 4];           // sorted contributions: (query slot, weight bits)
+  __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
+  __shared__ uint32_t s_hist[TP];           // contributions per pixel (this chunk)
+  __shared__ uint32_t s_base[TP + 4];       // exclusive prefix of s_hist
+  __shared__ uint32_t s_q[CQ];              // query index of each chunk slot
+  __shared__ uint32_t s_hit[CQ];            // slot has a contribution or a home sample
+  __shared__ int s_H[MAXL], s_W[MAXL], s_lsi[MAXL], s_qoff[MAXL + 1], s_ioff[MAXL + 1];
+  __shared__ int s_cx0[MAXL], s_cy0[MAXL], s_cnx[MAXL], s_coff[MAXL + 1];
+  __shared__ float s_sx[MAXL], s_sy[MAXL];
+  __shared__ uint32_t s_hcount;
+
+  const int tid = threadIdx.x;
+  const uint32_t Lq = (uint32_t)S;
+  if (tid == 0) {
+    int qo = 0, io = 0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      s_H[l] = H;
+      s_W[l] = W;
+      s_lsi[l] = (int)lsi[l];
+      s_qoff[l] = qo;
+      s_ioff[l] = io;
+      qo += H * W;
+      io += N * M * ((H + T - 1) / T) * ((W + T - 1) / T);
+    }
+    s_qoff[L] = qo;
+    s_ioff[L] = io;
+  }
+  __syncthreads();
+  const int total_items = s_ioff[L];
+
+  for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+    int l = 0;
+    while (l + 1 < L && item >= s_ioff[l + 1]) ++l;
+    const int H = s_H[l], W = s_W[l];
+    const int ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
+    const int rem = item - s_ioff[l];
+    const int tile = rem % (ntx * nty), nm = rem / (ntx * nty);
+    const int m = nm % M, n = nm / M;
+    const int y0 = (tile / ntx) * T, x0 = (tile % ntx) * T;
+    const int th = min(T, H - y0), tw = min(T, W - x0);
+
+    if (tid == 0) {
+      int co = 0;
+      for (int lq = 0; lq < L; ++lq) {
+        const int Hq = s_H[lq], Wq = s_W[lq];
+        const float sx = level_scale(W, Wq), sy = level_scale(H, Hq);
+        s_sx[lq] = sx;
+        s_sy[lq] = sy;
+        // queries whose nominal centre c satisfies  x0 - 1 - R <= c < x0 + tw + R  (a near
+        // sample of any other query cannot have a corner inside the tile); +-1 query of slack.
+        int xa = (int)floorf(((float)x0 - 0.5f - NEAR_R) / sx - 0.5f) - 1;
+        int xb = (int)ceilf(((float)(x0 + tw) + 0.5f + NEAR_R) / sx - 0.5f) + 1;
+        int ya = (int)floorf(((float)y0 - 0.5f - NEAR_R) / sy - 0.5f) - 1;
+        int yb = (int)ceilf(((float)(y0 + th) + 0.5f + NEAR_R) / sy - 0.5f) + 1;
+        xa = max(xa, 0);
+        ya = max(ya, 0);
+        xb = min(xb, Wq - 1);
+        yb = min(yb, Hq - 1);
+        const int nx = max(xb - xa + 1, 0), ny = max(yb - ya + 1, 0);
+        s_cx0[lq] = xa;
+        s_cy0[lq] = ya;
+        s_cnx[lq] = nx;
+        s_coff[lq] = co;
+        co += nx * ny;
+      }
+      s_coff[L] = co;
+      s_hcount = 0;
+    }
+    // value tile -> LDS (zeros outside the level), counters cleared
+    {
+      const uint32_t lrow = (uint32_t)n * (uint32_t)S + (uint32_t)s_lsi[l];
+      for (int t = tid; t < (ZROW + 1) * 8; t += NT) {
+        const int row = t >> 3, sub = t & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < ZROW) {
+          const int y = y0 + row / VT, x = x0 + row % VT;
+          if (y < H && x < W)
+            v = ld16(value, ((lrow + (uint32_t)(y * W + x)) * (uint32_t)M + (uint32_t)m) * 128u +
+                                (uint32_t)sub * 16u);
+        }
+        s_vt[row * 8 + (sub ^ (row & 7))] = v;
+      }
+      for (int t = tid; t < TP; t += NT) s_hist[t] = 0;
+      for (int t = tid; t < CQ; t += NT) s_hit[t] = 0;
+    }
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int NC = s_coff[L];
+
+    for (int c0 = 0; c0 < NC; c0 += CQ) {
+      // ---------------- phase A: examine one candidate sample per thread ----------------
+      const int ql = tid >> 2, p = tid & 3;
+      bool own1 = false, own2 = false, own3 = false, own4 = false, home = false;
+      uint32_t pos1 = 0, pos2 = 0, pos3 = 0, pos4 = 0;
+      int r1 = 0;
+      float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+      float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + ql < NC) {
+        const int c = c0 + ql;
+        int lq = 0;
+        while (lq + 1 < L && c >= s_coff[lq + 1]) ++lq;
+        const int cc = c - s_coff[lq], nx = s_cnx[lq];
+        const int yq = s_cy0[lq] + cc / nx, xq = s_cx0[lq] + cc % nx;
+        const uint32_t q = (uint32_t)(s_qoff[lq] + yq * s_W[lq] + xq);
+        if (p == 0) s_q[ql] = q;
+        const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
+        const uint32_t s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (uint32_t)p;
+        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
+        const float a = aw[s];
+        const Corner4<float> g = corner_setup<float>(xy.x, xy.y, H, W);
+        const float cx = nominal_centre(xq, s_sx[lq]), cy = nominal_centre(yq, s_sy[lq]);
+        if (!g.in) {
+          // gate closed: zero gradients, written by the tile holding the nominal centre
+          const int px = min(max((int)floorf(cx + 0.5f), 0), W - 1) - x0;
+          const int py = min(max((int)floorf(cy + 0.5f), 0), H - 1) - y0;
+          if ((unsigned)px < (unsigned)tw && (unsigned)py < (unsigned)th) {
+            grad_aw[s] = 0.f;
+            *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2(0.f, 0.f);
+          }
+        } else if (is_near(g, cx, cy)) {
+          const int ly0 = g.h0 - y0, lx0 = g.w0 - x0;       // corner 1 in tile coordinates
+          const bool yin0 = (unsigned)ly0 < (unsigned)th, yin1 = (unsigned)(ly0 + 1) < (unsigned)th;
+          const bool xin0 = (unsigned)lx0 < (unsigned)tw, xin1 = (unsigned)(lx0 + 1) < (unsigned)tw;
+          own1 = g.ok1 && yin0 && xin0;
+          own2 = g.ok2 && yin0 && xin1;
+          own3 = g.ok3 && yin1 && xin0;
+          own4 = g.ok4 && yin1 && xin1;
+          r1 = ly0 * T + lx0;
+          if (own1) pos1 = atomicAdd(&s_hist[r1], 1u);
+          if (own2) pos2 = atomicAdd(&s_hist[r1 + 1], 1u);
+          if (own3) pos3 = atomicAdd(&s_hist[r1 + T], 1u);
+          if (own4) pos4 = atomicAdd(&s_hist[r1 + T + 1], 1u);
+          w1 = g.k1 * a;
+          w2 = g.k2 * a;
+          w3 = g.k3 * a;
+          w4 = g.k4 * a;
+          const int hy = max(g.h0, 0) - y0, hx = max(g.w0, 0) - x0;
+          home = (unsigned)hy < (unsigned)th && (unsigned)hx < (unsigned)tw;
+          if (home) {
+            const uint32_t ok = (g.ok1 ? 1u : 0u) | (g.ok2 ? 2u : 0u) | (g.ok3 ? 4u : 0u) |
+                                (g.ok4 ? 8u : 0u);
+            const uint32_t pk = (uint32_t)(ly0 + 1) | ((uint32_t)(lx0 + 1) << 5) | (ok << 10) |
+                                ((uint32_t)tid << 14);
+            hrec = make_float4(g.lh, g.lw, a, __uint_as_float(pk));
+          }
+          if (own1 || own2 || own3 || own4 || home) s_hit[ql] = 1u;
+        }
+      }
+      __syncthreads();
+      // ---------------- phase B: prefix sum (wave 0) + stage grad_output rows ----------------
+      if (tid < 64) {
+        const uint4 c = reinterpret_cast<uint4 *>(s_hist)[tid];
+        const uint32_t sum = c.x + c.y + c.z + c.w;
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t t = __shfl_up(incl, off);
+          if (tid >= off) incl += t;
+        }
+        const uint32_t excl = incl - sum;
+        reinterpret_cast<uint4 *>(s_base)[tid] =
+            make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
+        if (tid == 63) s_base[TP] = incl;
+        reinterpret_cast<uint4 *>(s_hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      for (int t = tid; t < CQ * 8; t += NT) {
+        const int slot = t >> 3, sub = t & 7;
+        if (s_hit[slot]) {
+          const uint32_t q = s_q[slot];
+          s_go[slot * 8 + (sub ^ (slot & 7))] =
+              ld16(grad_out, (((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m) * 128u +
+                                 (uint32_t)sub * 16u);
+        }
+      }
+      __syncthreads();
+      // ---------------- phase C: scatter contributions into pixel order ----------------
+      if (own1) s_rec[s_base[r1] + pos1] = make_uint2((uint32_t)ql, __float_as_uint(w1));
+      if (own2) s_rec[s_base[r1 + 1] + pos2] = make_uint2((uint32_t)ql, __float_as_uint(w2));
+      if (own3) s_rec[s_base[r1 + T] + pos3] = make_uint2((uint32_t)ql, __float_as_uint(w3));
+      if (own4) s_rec[s_base[r1 + T + 1] + pos4] = make_uint2((uint32_t)ql, __float_as_uint(w4));
+      if (home) s_home[atomicAdd(&s_hcount, 1u)] = hrec;
+      if (tid < CQ) s_hit[tid] = 0u;
+      __syncthreads();
+      // ---------------- phase D: every pixel's owners sum their list ----------------
+      {
+        const int px = tid >> 1, half = tid & 1;
+        const uint32_t b0 = s_base[px], b1 = s_base[px + 1];
+        for (uint32_t i = b0; i < b1; ++i) {
+          const uint2 rc = s_rec[i];
+          const float w = __uint_as_float(rc.y);
+          const int row = (int)rc.x;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 gv = s_go[row * 8 + ((half * 4 + k) ^ (row & 7))];
+            acc[k].x += w * gv.x;
+            acc[k].y += w * gv.y;
+            acc[k].z += w * gv.z;
+            acc[k].w += w * gv.w;
+          }
+        }
+      }
+      // ---------------- phase E: gradients of the samples this tile is home to ----------------
+      {
+        const uint32_t hc = s_hcount;
+        const int sub = tid & 7;
+        for (uint32_t h = (uint32_t)tid >> 3; h < ((hc + 7u) & ~7u) && h < (uint32_t)NT; h += NT / 8) {
+          // (all 8 lanes of a group share h, so the whole group is in or out together)
+          const bool live = h < hc;
+          const float4 hr = s_home[live ? h : 0u];
+          const uint32_t pk = __float_as_uint(hr.w);
+          const int by = (int)(pk & 31u) - 1, bx = (int)((pk >> 5) & 31u) - 1;
+          const uint32_t ok = (pk >> 10) & 15u, e = pk >> 14;
+          const int slot = (int)(e >> 2);
+          const float4 g4 = s_go[slot * 8 + (sub ^ (slot & 7))];
+          const int rb = by * VT + bx;
+          const int ra = (ok & 1u) ? rb : ZROW, rbb = (ok & 2u) ? rb + 1 : ZROW;
+          const int rc = (ok & 4u) ? rb + VT : ZROW, rd = (ok & 8u) ? rb + VT + 1 : ZROW;
+          const float4 v1 = s_vt[ra * 8 + (sub ^ (ra & 7))];
+          const float4 v2 = s_vt[rbb * 8 + (sub ^ (rbb & 7))];
+          const float4 v3 = s_vt[rc * 8 + (sub ^ (rc & 7))];
+          const float4 v4 = s_vt[rd * 8 + (sub ^ (rd & 7))];
+          float d1 = g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w;
+          float d2 = g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w;
+          float d3 = g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w;
+          float d4 = g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+#pragma unroll
+          for (int off = 1; off < 8; off <<= 1) {
+            d1 += __shfl_xor(d1, off);
+            d2 += __shfl_xor(d2, off);
+            d3 += __shfl_xor(d3, off);
+            d4 += __shfl_xor(d4, off);
+          }
+          if (live && sub == 0) {
+            const float lh = hr.x, lw = hr.y, a = hr.z, hh = 1.f - lh, hw = 1.f - lw;
+            const uint32_t q = s_q[slot];
+            const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
+            const uint32_t s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (e & 3u);
+            grad_aw[s] = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
+            const float gw = (float)W * a * (hh * (d2 - d1) + lh * (d4 - d3));
+            const float gh = (float)H * a * (hw * (d3 - d1) + lw * (d4 - d2));
+            *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2(gw, gh);
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) s_hcount = 0;   // next push happens two barriers from here
+    }
+    // ---------------- flush the tile's grad_value rows (sole owner: plain stores) ----------------
+    {
+      const int px = tid >> 1, half = tid & 1;
+      const int py = px / T, pxx = px % T;
+      if (py < th && pxx < tw) {
+        const uint32_t rowi = (uint32_t)n * (uint32_t)S + (uint32_t)s_lsi[l] +
+                              (uint32_t)((y0 + py) * W + x0 + pxx);
+        float4 *dst = reinterpret_cast<float4 *>(
+            reinterpret_cast<char *>(grad_value) +
+            ((size_t)(rowi * (uint32_t)M + (uint32_t)m) * 128u + (size_t)half * 64u));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = acc[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Second pass of the tiled backward: samples that are in range but not *near* their
+// query's nominal centre (see above).  One lane examines one sample; the wave then takes
+// its far samples two at a time (one per half-wave, lane = channel) and treats them like
+// the generic kernel: hardware float atomics into grad_value (which the first pass has
+// fully written by then -- same stream), shuffle-reduced grad_sampling_loc/grad_attn_weight.
+// Every sample is scanned (sampling_loc is re-read once); nothing to do when all are near.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msda_bwd_far_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int L,
+    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
+  __shared__ int s_H[MAXL], s_W[MAXL], s_lsi[MAXL], s_qoff[MAXL + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) {
+    int qo = 0;
+    for (int l = 0; l < L; ++l) {
+      s_H[l] = (int)shapes[2 * l];
+      s_W[l] = (int)shapes[2 * l + 1];
+      s_lsi[l] = (int)lsi[l];
+      s_qoff[l] = qo;
+      qo += s_H[l] * s_W[l];
+    }
+    s_qoff[L] = qo;
+  }
+  __syncthreads();
+  const uint32_t Lq = (uint32_t)S;
+  const uint32_t nsamples = (uint32_t)N * Lq * (uint32_t)M * (uint32_t)L * 4u;
+  const uint32_t stride = gridDim.x * 256u;
+  const uint32_t nrounds = (nsamples + stride - 1u) / stride;
+  for (uint32_t round = 0; round < nrounds; ++round) {
+    const uint32_t s = round * stride + blockIdx.x * 256u + (uint32_t)tid;
+    bool far = false;
+    uint32_t vrow = 0, pair = 0;
+    int W = 1, H = 1;
+    float a = 0.f;
+    Corner4<float> g = {};
+    uint32_t okbits = 0;
+    if (s < nsamples) {
+      const uint32_t t = s >> 2;
+      const int l = (int)(t % (uint32_t)L);
+      pair = t / (uint32_t)L;
+      const uint32_t m = pair % (uint32_t)M, nq = pair / (uint32_t)M;
+      const uint32_t q = nq % Lq, n = nq / Lq;
+      int lq = 0;
+      while (lq + 1 < L && (int)q >= s_qoff[lq + 1]) ++lq;
+      const int Wq = s_W[lq], Hq = s_H[lq];
+      const int qq = (int)q - s_qoff[lq];
+      const int yq = qq / Wq, xq = qq % Wq;
+      H = s_H[l];
+      W = s_W[l];
+      const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
+      g = corner_setup<float>(xy.x, xy.y, H, W);
+      const float cx = nominal_centre(xq, level_scale(W, Wq));
+      const float cy = nominal_centre(yq, level_scale(H, Hq));
+      far = g.in && !is_near(g, cx, cy);
+      if (far) a = aw[s];
+      okbits = (g.ok1 ? 1u : 0u) | (g.ok2 ? 2u : 0u) | (g.ok3 ? 4u : 0u) | (g.ok4 ? 8u : 0u);
+      vrow = (n * (uint32_t)S + (uint32_t)s_lsi[l]) * (uint32_t)M + m;   // row of pixel 0
+    }
+    unsigned long long mask = __ballot(far);
+    while (mask) {
+      const int sa = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      int sb = -1;
+      if (mask) {
+        sb = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+      }
+      const bool act = lane < 32 || sb >= 0;
+      const int src = (lane < 32 || sb < 0) ? sa : sb;
+      const int ch = lane & 31;
+      const uint32_t s_s = __shfl(s, src), pair_s = __shfl(pair, src), vrow_s = __shfl(vrow, src);
+      const int W_s = __shfl(W, src), H_s = __shfl(H, src);
+      const float a_s = __shfl(a, src), lh = __shfl(g.lh, src), lw = __shfl(g.lw, src);
+      const float k1 = __shfl(g.k1, src), k2 = __shfl(g.k2, src), k3 = __shfl(g.k3, src),
+                  k4 = __shfl(g.k4, src);
+      const int o1 = __shfl(g.o1, src), o2 = __shfl(g.o2, src), o3 = __shfl(g.o3, src),
+                o4 = __shfl(g.o4, src);
+      const uint32_t ok = __shfl(okbits, src);
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      float ga = 0.f, gw = 0.f, gh = 0.f;
+      if (act) {
+        const uint32_t rowf = (uint32_t)M * 32u;
+        const float tg = grad_out[pair_s * 32u + (uint32_t)ch], tgv = tg * a_s;
+        const uint32_t base = vrow_s * 32u + (uint32_t)ch;
+        // an in-level corner takes part even when its weight is exactly 0 (its value still
+        // enters d/d loc); out-of-level corners read as 0 and scatter nothing
+        const float v1 = (ok & 1u) ? value[base + (uint32_t)o1 * rowf] : 0.f;
+        const float v2 = (ok & 2u) ? value[base + (uint32_t)o2 * rowf] : 0.f;
+        const float v3 = (ok & 4u) ? value[base + (uint32_t)o3 * rowf] : 0.f;
+        const float v4 = (ok & 8u) ? value[base + (uint32_t)o4 * rowf] : 0.f;
+        if (ok & 1u) atomicAdd(grad_value + base + (uint32_t)o1 * rowf, k1 * tgv);
+        if (ok & 2u) atomicAdd(grad_value + base + (uint32_t)o2 * rowf, k2 * tgv);
+        if (ok & 4u) atomicAdd(grad_value + base + (uint32_t)o3 * rowf, k3 * tgv);
+        if (ok & 8u) atomicAdd(grad_value + base + (uint32_t)o4 * rowf, k4 * tgv);
+        ga = tg * (k1 * v1 + k2 * v2 + k3 * v3 + k4 * v4);
+        gw = tgv * (hh * (v2 - v1) + lh * (v4 - v3));
+        gh = tgv * (hw * (v3 - v1) + lw * (v4 - v2));
+      }
+      ga = group_sum<float, 32>(ga);
+      gw = group_sum<float, 32>(gw);
+      gh = group_sum<float, 32>(gh);
+      if (act && ch == 0) {
+        grad_aw[s_s] = ga;
+        *reinterpret_cast<float2 *>(grad_loc + 2u * s_s) = make_float2((float)W_s * gw, (float)H_s * gh);
+      }
+    }
+  }
+}
+
+}  // namespace tiled
+
 // ---------------------------------------------------------------------------------------
 // Host side.
 // ---------------------------------------------------------------------------------------
@@ -413,12 +870,31 @@ int forward_impl<float>(const float *value, const int64_t *shapes, const int64_t
   return forward_generic<float>(value, shapes, lsi, loc, aw, N, S, M, D, L, Lq, P, out, st);
 }
 
+int num_cus() {
+  static thread_local int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev != cached_dev) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    cached = v;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
+// MSDA_BWD_IMPL=generic forces the atomic kernel (A/B measurements); default picks by shape.
+bool tiled_allowed() {
+  const char *e = getenv("MSDA_BWD_IMPL");
+  return !(e && strcmp(e, "generic") == 0);
+}
+
 template <typename T>
-int backward_impl(const char *who, const T *value, const int64_t *shapes, const int64_t *lsi,
-                  const T *loc, const T *aw, const T *grad_out, int N, int S, int M, int D,
-                  int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_aw, void *stream) {
-  if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
+int backward_atomic(const char *who, const T *value, const int64_t *shapes, const int64_t *lsi,
+                    const T *loc, const T *aw, const T *grad_out, int N, int S, int M, int D,
+                    int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_aw,
+                    hipStream_t st) {
   const size_t vbytes = sizeof(T) * (size_t)N * S * M * D;
   if (vbytes) {
     const hipError_t e = hipMemsetAsync(grad_value, 0, vbytes, st);
@@ -429,6 +905,52 @@ int backward_impl(const char *who, const T *value, const int64_t *shapes, const 
   if ((size_t)N * Lq == 0) return MSDA_OK;
   return backward_generic<T>(value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P,
                              grad_value, grad_loc, grad_aw, st);
+}
+
+template <typename T>
+int backward_impl(const char *who, const T *value, const int64_t *shapes, const int64_t *lsi,
+                  const T *loc, const T *aw, const T *grad_out, int N, int S, int M, int D,
+                  int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_aw, void *stream);
+
+template <>
+int backward_impl<double>(const char *who, const double *value, const int64_t *shapes,
+                          const int64_t *lsi, const double *loc, const double *aw,
+                          const double *grad_out, int N, int S, int M, int D, int L, int Lq,
+                          int P, double *grad_value, double *grad_loc, double *grad_aw,
+                          void *stream) {
+  if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
+  return backward_atomic<double>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq,
+                                 P, grad_value, grad_loc, grad_aw,
+                                 static_cast<hipStream_t>(stream));
+}
+
+template <>
+int backward_impl<float>(const char *who, const float *value, const int64_t *shapes,
+                         const int64_t *lsi, const float *loc, const float *aw,
+                         const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                         float *grad_value, float *grad_loc, float *grad_aw, void *stream) {
+  if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t npairs = (size_t)N * Lq * M;
+  const size_t limit = (size_t)1 << 30;
+  const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit;
+  // Encoder self-attention shape (one query per pixel of every level): destination-tiled
+  // kernels.  The caller guarantees sum(H_l * W_l) == S, as the reference requires for memory
+  // safety (ops/modules/ms_deform_attn.py:96).
+  if (D == 32 && P == tiled::P && Lq == S && Lq > 0 && N > 0 && L <= tiled::MAXL && small &&
+      aligned16(value) && aligned16(grad_out) && aligned16(grad_value) && aligned16(loc) &&
+      aligned16(grad_loc) && tiled_allowed()) {
+    const int cus = num_cus();
+    hipLaunchKernelGGL(tiled::msda_bwd_tiled_kernel, dim3(2 * cus), dim3(tiled::NT), 0, st,
+                       grad_out, value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc,
+                       grad_aw);
+    if (int rc = check_launch(who)) return rc;
+    hipLaunchKernelGGL(tiled::msda_bwd_far_kernel, dim3(8 * cus), dim3(256), 0, st, grad_out,
+                       value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc, grad_aw);
+    return check_launch(who);
+  }
+  return backward_atomic<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P,
+                                grad_value, grad_loc, grad_aw, st);
 }
 
 }  // namespace
