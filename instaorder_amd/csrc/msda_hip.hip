@@ -338,6 +338,19 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
 // =======================================================================================
 namespace tiled {
 
+// Diagnostic build only (-DMSDA_PHASE_STAMPS): per-phase shader-clock sums of the tiled
+// backward, accumulated per wave and added to a device array that no kernel reads.
+#ifdef MSDA_PHASE_STAMPS
+__device__ unsigned long long g_phase_cycles[16];
+#define MSDA_STAMP_DECL unsigned long long st_last = clock64(), st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MSDA_STAMP(i) { const unsigned long long st_now = clock64(); st_ph[i] += st_now - st_last; st_last = st_now; }
+#define MSDA_STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], st_ph[i]); }
+#else
+#define MSDA_STAMP_DECL
+#define MSDA_STAMP(i)
+#define MSDA_STAMP_FLUSH
+#endif
+
 constexpr int T = 16;             // tile side, pixels of the sampled level
 constexpr int TP = T * T;         // pixels per tile
 constexpr int VT = T + 1;         // value tile side (a home sample reaches one pixel further)
@@ -359,6 +372,15 @@ __device__ __forceinline__ bool is_near(const Corner4<float> &g, float cx, float
   return g.in && fabsf(g.w_im - cx) <= NEAR_R && fabsf(g.h_im - cy) <= NEAR_R;
 }
 
+// Sum over the 8 lanes of an aligned lane group, entirely in DPP (no LDS round trip):
+// xor-1 and xor-2 as quad permutes, then row_half_mirror brings in the other quad's total.
+__device__ __forceinline__ float sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
 __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
@@ -370,12 +392,11 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
   __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
   __shared__ uint32_t s_hist[TP];           // contributions per pixel (this chunk)
   __shared__ uint32_t s_base[TP + 4];       // exclusive prefix of s_hist
-  __shared__ uint32_t s_q[CQ];              // query index of each chunk slot
-  __shared__ uint32_t s_hit[CQ];            // slot has a contribution or a home sample
+  __shared__ uint32_t s_q[2 * CQ];          // query index of each chunk slot, by chunk parity
   __shared__ int s_H[MAXL], s_W[MAXL], s_lsi[MAXL], s_qoff[MAXL + 1], s_ioff[MAXL + 1];
   __shared__ int s_cx0[MAXL], s_cy0[MAXL], s_cnx[MAXL], s_coff[MAXL + 1];
-  __shared__ float s_sx[MAXL], s_sy[MAXL];
-  __shared__ uint32_t s_hcount;
+  __shared__ float s_sx[MAXL], s_sy[MAXL], s_cinv[MAXL];
+  __shared__ uint32_t s_hcount[2];
 
   const int tid = threadIdx.x;
   const uint32_t Lq = (uint32_t)S;
@@ -396,6 +417,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
   }
   __syncthreads();
   const int total_items = s_ioff[L];
+  MSDA_STAMP_DECL
 
   for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
     int l = 0;
@@ -429,11 +451,13 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
         s_cx0[lq] = xa;
         s_cy0[lq] = ya;
         s_cnx[lq] = nx;
+        s_cinv[lq] = 1.0f / (float)max(nx, 1);
         s_coff[lq] = co;
         co += nx * ny;
       }
       s_coff[L] = co;
-      s_hcount = 0;
+      s_hcount[0] = 0;
+      s_hcount[1] = 0;
     }
     // value tile -> LDS (zeros outside the level), counters cleared
     {
@@ -450,7 +474,6 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
         s_vt[row * 8 + (sub ^ (row & 7))] = v;
       }
       for (int t = tid; t < TP; t += NT) s_hist[t] = 0;
-      for (int t = tid; t < CQ; t += NT) s_hit[t] = 0;
     }
     float4 acc[4];
 #pragma unroll
@@ -458,27 +481,70 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     __syncthreads();
     const int NC = s_coff[L];
 
-    for (int c0 = 0; c0 < NC; c0 += CQ) {
+    // Candidate c -> (query level, query pixel, query index).  The row/column split uses a
+    // float reciprocal: (cc + 0.5) / nx is at least 0.5 / nx away from an integer, far more
+    // than the rounding error for the few thousand candidates of a rectangle.
+    auto decode = [&](int c, int &lq, int &yq, int &xq) -> uint32_t {
+      lq = 0;
+      while (lq + 1 < L && c >= s_coff[lq + 1]) ++lq;
+      const int cc = c - s_coff[lq], nx = s_cnx[lq];
+      const int row = (int)(((float)cc + 0.5f) * s_cinv[lq]);
+      yq = s_cy0[lq] + row;
+      xq = s_cx0[lq] + (cc - row * nx);
+      return (uint32_t)(s_qoff[lq] + yq * s_W[lq] + xq);
+    };
+    // Software pipeline.  While chunk i is sorted and consumed out of LDS, the sampling
+    // location / weight of chunk i+1's sample are already in flight (requested in phase A of
+    // chunk i) and so are the grad_output rows of chunk i+1's queries (requested in phase B
+    // of chunk i, once their indices are visible in s_q).  s_q[parity] of chunk i+1 is written
+    // in phase B of chunk i: by then (barrier 1) nobody reads chunk i-1's copy any more.
+    const int ql = tid >> 2, p = tid & 3;
+    const int gslot = tid >> 3, gsub = tid & 7;          // grad_output rows: slots gslot, gslot+64
+    bool n_valid = false;
+    int n_lq = 0, n_yq = 0, n_xq = 0;
+    uint32_t n_s = 0, n_q = 0;
+    float2 n_xy = make_float2(0.f, 0.f);
+    float n_a = 0.f;
+    float4 n_g0 = make_float4(0.f, 0.f, 0.f, 0.f), n_g1 = n_g0;
+    auto prefetch_sample = [&](int c0) {
+      n_valid = c0 + ql < NC;
+      if (n_valid) {
+        const uint32_t q = decode(c0 + ql, n_lq, n_yq, n_xq);
+        n_q = q;
+        const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
+        n_s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (uint32_t)p;
+        n_xy = *reinterpret_cast<const float2 *>(loc + 2u * n_s);
+        n_a = aw[n_s];
+      }
+    };
+    auto prefetch_rows = [&](int c0, int buf) {
+      if (c0 + gslot < NC)
+        n_g0 = ld16(grad_out, (((uint32_t)n * Lq + s_q[buf * CQ + gslot]) * (uint32_t)M +
+                               (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
+      if (c0 + gslot + 64 < NC)
+        n_g1 = ld16(grad_out, (((uint32_t)n * Lq + s_q[buf * CQ + gslot + 64]) * (uint32_t)M +
+                               (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
+    };
+    if (NC > 0) {
+      prefetch_sample(0);
+      if (n_valid && p == 0) s_q[ql] = n_q;
+    }
+    MSDA_STAMP(0)   // item setup: value tile, candidate rectangles, first prefetch
+
+    for (int c0 = 0, chunk = 0; c0 < NC; c0 += CQ, ++chunk) {
       // ---------------- phase A: examine one candidate sample per thread ----------------
-      const int ql = tid >> 2, p = tid & 3;
+      const int qbuf = chunk & 1, qnext = qbuf ^ 1;      // s_q / s_hcount parity of this chunk
+      const int hbuf = qbuf;
       bool own1 = false, own2 = false, own3 = false, own4 = false, home = false;
       uint32_t pos1 = 0, pos2 = 0, pos3 = 0, pos4 = 0;
       int r1 = 0;
       float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
       float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + ql < NC) {
-        const int c = c0 + ql;
-        int lq = 0;
-        while (lq + 1 < L && c >= s_coff[lq + 1]) ++lq;
-        const int cc = c - s_coff[lq], nx = s_cnx[lq];
-        const int yq = s_cy0[lq] + cc / nx, xq = s_cx0[lq] + cc % nx;
-        const uint32_t q = (uint32_t)(s_qoff[lq] + yq * s_W[lq] + xq);
-        if (p == 0) s_q[ql] = q;
-        const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
-        const uint32_t s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (uint32_t)p;
-        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
-        const float a = aw[s];
-        const Corner4<float> g = corner_setup<float>(xy.x, xy.y, H, W);
+      if (n_valid) {
+        const uint32_t s = n_s;
+        const float a = n_a;
+        const int lq = n_lq, yq = n_yq, xq = n_xq;
+        const Corner4<float> g = corner_setup<float>(n_xy.x, n_xy.y, H, W);
         const float cx = nominal_centre(xq, s_sx[lq]), cy = nominal_centre(yq, s_sy[lq]);
         if (!g.in) {
           // gate closed: zero gradients, written by the tile holding the nominal centre
@@ -514,11 +580,18 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
                                 ((uint32_t)tid << 14);
             hrec = make_float4(g.lh, g.lw, a, __uint_as_float(pk));
           }
-          if (own1 || own2 || own3 || own4 || home) s_hit[ql] = 1u;
         }
       }
-      __syncthreads();
-      // ---------------- phase B: prefix sum (wave 0) + stage grad_output rows ----------------
+      const bool more = c0 + CQ < NC;
+      if (more) prefetch_sample(c0 + CQ);
+      MSDA_STAMP(1)   // phase A
+      __syncthreads();   // every wave is past phases D/E of the previous chunk
+      MSDA_STAMP(2)   // barrier 1
+      // ------- phase B: grad_output rows -> LDS, next rows requested, prefix sum (wave 0) -------
+      if (chunk == 0) prefetch_rows(c0, qbuf);           // first chunk of an item: not in flight yet
+      s_go[gslot * 8 + (gsub ^ (gslot & 7))] = n_g0;
+      s_go[(gslot + 64) * 8 + (gsub ^ ((gslot + 64) & 7))] = n_g1;
+      if (more && n_valid && p == 0) s_q[qnext * CQ + ql] = n_q;
       if (tid < 64) {
         const uint4 c = reinterpret_cast<uint4 *>(s_hist)[tid];
         const uint32_t sum = c.x + c.y + c.z + c.w;
@@ -533,25 +606,19 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
             make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
         if (tid == 63) s_base[TP] = incl;
         reinterpret_cast<uint4 *>(s_hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
-      }
-      for (int t = tid; t < CQ * 8; t += NT) {
-        const int slot = t >> 3, sub = t & 7;
-        if (s_hit[slot]) {
-          const uint32_t q = s_q[slot];
-          s_go[slot * 8 + (sub ^ (slot & 7))] =
-              ld16(grad_out, (((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m) * 128u +
-                                 (uint32_t)sub * 16u);
-        }
+        if (tid == 0) s_hcount[hbuf ^ 1] = 0u;           // the next chunk's home counter
       }
       __syncthreads();
+      MSDA_STAMP(3)   // phase B + barrier 2
       // ---------------- phase C: scatter contributions into pixel order ----------------
       if (own1) s_rec[s_base[r1] + pos1] = make_uint2((uint32_t)ql, __float_as_uint(w1));
       if (own2) s_rec[s_base[r1 + 1] + pos2] = make_uint2((uint32_t)ql, __float_as_uint(w2));
       if (own3) s_rec[s_base[r1 + T] + pos3] = make_uint2((uint32_t)ql, __float_as_uint(w3));
       if (own4) s_rec[s_base[r1 + T + 1] + pos4] = make_uint2((uint32_t)ql, __float_as_uint(w4));
-      if (home) s_home[atomicAdd(&s_hcount, 1u)] = hrec;
-      if (tid < CQ) s_hit[tid] = 0u;
+      if (home) s_home[atomicAdd(&s_hcount[hbuf], 1u)] = hrec;
+      if (more) prefetch_rows(c0 + CQ, qnext);
       __syncthreads();
+      MSDA_STAMP(4)   // phase C + barrier 3
       // ---------------- phase D: every pixel's owners sum their list ----------------
       {
         const int px = tid >> 1, half = tid & 1;
@@ -570,14 +637,14 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           }
         }
       }
+      MSDA_STAMP(5)   // phase D
       // ---------------- phase E: gradients of the samples this tile is home to ----------------
       {
-        const uint32_t hc = s_hcount;
+        const uint32_t hc = s_hcount[hbuf];
         const int sub = tid & 7;
-        for (uint32_t h = (uint32_t)tid >> 3; h < ((hc + 7u) & ~7u) && h < (uint32_t)NT; h += NT / 8) {
-          // (all 8 lanes of a group share h, so the whole group is in or out together)
-          const bool live = h < hc;
-          const float4 hr = s_home[live ? h : 0u];
+        // all 8 lanes of a group share h, so a group is in or out of the loop together
+        for (uint32_t h = (uint32_t)tid >> 3; h < hc; h += NT / 8) {
+          const float4 hr = s_home[h];
           const uint32_t pk = __float_as_uint(hr.w);
           const int by = (int)(pk & 31u) - 1, bx = (int)((pk >> 5) & 31u) - 1;
           const uint32_t ok = (pk >> 10) & 15u, e = pk >> 14;
@@ -590,20 +657,13 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           const float4 v2 = s_vt[rbb * 8 + (sub ^ (rbb & 7))];
           const float4 v3 = s_vt[rc * 8 + (sub ^ (rc & 7))];
           const float4 v4 = s_vt[rd * 8 + (sub ^ (rd & 7))];
-          float d1 = g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w;
-          float d2 = g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w;
-          float d3 = g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w;
-          float d4 = g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
-#pragma unroll
-          for (int off = 1; off < 8; off <<= 1) {
-            d1 += __shfl_xor(d1, off);
-            d2 += __shfl_xor(d2, off);
-            d3 += __shfl_xor(d3, off);
-            d4 += __shfl_xor(d4, off);
-          }
-          if (live && sub == 0) {
+          const float d1 = sum8(g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w);
+          const float d2 = sum8(g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w);
+          const float d3 = sum8(g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w);
+          const float d4 = sum8(g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w);
+          if (sub == 0) {
             const float lh = hr.x, lw = hr.y, a = hr.z, hh = 1.f - lh, hw = 1.f - lw;
-            const uint32_t q = s_q[slot];
+            const uint32_t q = s_q[qbuf * CQ + slot];
             const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
             const uint32_t s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (e & 3u);
             grad_aw[s] = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
@@ -613,8 +673,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           }
         }
       }
-      __syncthreads();
-      if (tid == 0) s_hcount = 0;   // next push happens two barriers from here
+      MSDA_STAMP(6)   // phase E
     }
     // ---------------- flush the tile's grad_value rows (sole owner: plain stores) ----------------
     {
@@ -631,7 +690,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       }
     }
     __syncthreads();
+    MSDA_STAMP(0)
   }
+  MSDA_STAMP_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------
@@ -956,6 +1017,16 @@ int backward_impl<float>(const char *who, const float *value, const int64_t *sha
 }  // namespace
 
 extern "C" {
+
+#ifdef MSDA_PHASE_STAMPS
+// diagnostic build only: read (and clear) the per-phase cycle sums
+int msda_debug_phase_cycles(unsigned long long *out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(tiled::g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(tiled::g_phase_cycles), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int msda_abi_version(void) { return 1; }
 
