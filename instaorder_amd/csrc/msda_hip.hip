@@ -359,6 +359,8 @@ constexpr int NT = 512;           // threads per workgroup (2 workgroups per CU 
 constexpr int P = 4;              // points per level on this path
 constexpr int CQ = NT / P;        // candidate queries per chunk: one sample per thread
 constexpr int MAXL = 8;
+constexpr int LATX = 16, LATY = CQ / LATX;   // query lattice of one chunk (LATX * LATY == CQ)
+constexpr int KB = 8;             // bucket depth: contributions per pixel per round
 constexpr float NEAR_R = 6.0f;    // pixels; see the near/far contract above
 
 // Nominal centre of query pixel `xq` (level of width Wq) in the coordinates of the sampled
@@ -388,15 +390,14 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
   __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile, 16-B chunks XOR-swizzled by row
   __shared__ float4 s_go[CQ * 8];           // grad_output rows of this chunk's queries (swizzled)
-  __shared__ uint2 s_rec[NT * 4];           // sorted contributions: (query slot, weight bits)
+  __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (query slot, weight bits)
   __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
-  __shared__ uint32_t s_hist[TP];           // contributions per pixel (this chunk)
-  __shared__ uint32_t s_base[TP + 4];       // exclusive prefix of s_hist
-  __shared__ uint32_t s_q[2 * CQ];          // query index of each chunk slot, by chunk parity
-  __shared__ int s_H[MAXL], s_W[MAXL], s_lsi[MAXL], s_qoff[MAXL + 1], s_ioff[MAXL + 1];
-  __shared__ int s_cx0[MAXL], s_cy0[MAXL], s_cnx[MAXL], s_coff[MAXL + 1];
-  __shared__ float s_sx[MAXL], s_sy[MAXL], s_cinv[MAXL];
+  __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
+  __shared__ uint32_t s_max[2];             // highest bucket position (only set on overflow)
   __shared__ uint32_t s_hcount[2];
+  __shared__ int s_H[MAXL], s_W[MAXL], s_lsi[MAXL], s_qoff[MAXL + 1], s_ioff[MAXL + 1];
+  __shared__ int s_cx0[MAXL], s_cy0[MAXL], s_cnx[MAXL], s_cny[MAXL], s_SX[MAXL], s_SY[MAXL];
+  __shared__ float s_sx[MAXL], s_sy[MAXL];
 
   const int tid = threadIdx.x;
   const uint32_t Lq = (uint32_t)S;
@@ -419,6 +420,10 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
   const int total_items = s_ioff[L];
   MSDA_STAMP_DECL
 
+  const int ql = tid >> 2, p = tid & 3;                 // exam: query slot, point
+  const int qi = ql & (LATX - 1), qj = ql / LATX;       // slot position in the query lattice
+  const int gslot = tid >> 3, gsub = tid & 7;           // grad_output rows: slots gslot, gslot+64
+
   for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
     int l = 0;
     while (l + 1 < L && item >= s_ioff[l + 1]) ++l;
@@ -431,18 +436,18 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     const int th = min(T, H - y0), tw = min(T, W - x0);
 
     if (tid == 0) {
-      int co = 0;
       for (int lq = 0; lq < L; ++lq) {
         const int Hq = s_H[lq], Wq = s_W[lq];
         const float sx = level_scale(W, Wq), sy = level_scale(H, Hq);
         s_sx[lq] = sx;
         s_sy[lq] = sy;
-        // queries whose nominal centre c satisfies  x0 - 1 - R <= c < x0 + tw + R  (a near
-        // sample of any other query cannot have a corner inside the tile); +-1 query of slack.
-        int xa = (int)floorf(((float)x0 - 0.5f - NEAR_R) / sx - 0.5f) - 1;
-        int xb = (int)ceilf(((float)(x0 + tw) + 0.5f + NEAR_R) / sx - 0.5f) + 1;
-        int ya = (int)floorf(((float)y0 - 0.5f - NEAR_R) / sy - 0.5f) - 1;
-        int yb = (int)ceilf(((float)(y0 + th) + 0.5f + NEAR_R) / sy - 0.5f) + 1;
+        // Queries whose nominal centre c satisfies  x0 - 1 - R <= c < x0 + tw + R : a near
+        // sample of any other query cannot have a corner inside the tile.  c = (xq+.5)*sx-.5;
+        // the 0.01 px slack dwarfs the rounding of that expression.
+        int xa = (int)floorf(((float)x0 - 0.51f - NEAR_R) / sx - 0.5f);
+        int xb = (int)ceilf(((float)(x0 + tw) + 0.51f + NEAR_R) / sx - 0.5f);
+        int ya = (int)floorf(((float)y0 - 0.51f - NEAR_R) / sy - 0.5f);
+        int yb = (int)ceilf(((float)(y0 + th) + 0.51f + NEAR_R) / sy - 0.5f);
         xa = max(xa, 0);
         ya = max(ya, 0);
         xb = min(xb, Wq - 1);
@@ -451,13 +456,16 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
         s_cx0[lq] = xa;
         s_cy0[lq] = ya;
         s_cnx[lq] = nx;
-        s_cinv[lq] = 1.0f / (float)max(nx, 1);
-        s_coff[lq] = co;
-        co += nx * ny;
+        s_cny[lq] = (nx > 0) ? ny : 0;
+        // A chunk takes a LATX x LATY lattice of the rectangle with strides (SX, SY), so its
+        // samples spread over the whole tile and the per-pixel lists of a chunk stay short.
+        s_SX[lq] = max((nx + LATX - 1) / LATX, 1);
+        s_SY[lq] = max((ny + LATY - 1) / LATY, 1);
       }
-      s_coff[L] = co;
       s_hcount[0] = 0;
       s_hcount[1] = 0;
+      s_max[0] = 0;
+      s_max[1] = 0;
     }
     // value tile -> LDS (zeros outside the level), counters cleared
     {
@@ -473,79 +481,104 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
         }
         s_vt[row * 8 + (sub ^ (row & 7))] = v;
       }
-      for (int t = tid; t < TP; t += NT) s_hist[t] = 0;
+      for (int t = tid; t < 2 * (TP + 64); t += NT) (&s_cnt[0][0])[t] = 0;
     }
     float4 acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    const int NC = s_coff[L];
 
-    // Candidate c -> (query level, query pixel, query index).  The row/column split uses a
-    // float reciprocal: (cc + 0.5) / nx is at least 0.5 / nx away from an integer, far more
-    // than the rounding error for the few thousand candidates of a rectangle.
-    auto decode = [&](int c, int &lq, int &yq, int &xq) -> uint32_t {
-      lq = 0;
-      while (lq + 1 < L && c >= s_coff[lq + 1]) ++lq;
-      const int cc = c - s_coff[lq], nx = s_cnx[lq];
-      const int row = (int)(((float)cc + 0.5f) * s_cinv[lq]);
-      yq = s_cy0[lq] + row;
-      xq = s_cx0[lq] + (cc - row * nx);
-      return (uint32_t)(s_qoff[lq] + yq * s_W[lq] + xq);
+    // ---- candidate enumeration: (query level, lattice phase) -> one chunk ----
+    // `e` walks the chunks of this item; all of it is workgroup-uniform.  Slot (i, j) of a
+    // chunk is query (cx0 + phx + SX*i, cy0 + phy + SY*j) of level lq, valid while inside
+    // the candidate rectangle.
+    struct Enum {
+      int lq, phy, phx, SX, SY, nx, ny, cx0, cy0, Wq, qoff;
+      float sx, sy;
+    } e;
+    auto load_level = [&](int lq) {
+      while (lq < L && s_cny[lq] == 0) ++lq;
+      e.lq = lq;
+      e.phy = 0;
+      e.phx = 0;
+      if (lq < L) {
+        e.SX = s_SX[lq];
+        e.SY = s_SY[lq];
+        e.nx = s_cnx[lq];
+        e.ny = s_cny[lq];
+        e.cx0 = s_cx0[lq];
+        e.cy0 = s_cy0[lq];
+        e.Wq = s_W[lq];
+        e.qoff = s_qoff[lq];
+        e.sx = s_sx[lq];
+        e.sy = s_sy[lq];
+      }
     };
-    // Software pipeline.  While chunk i is sorted and consumed out of LDS, the sampling
-    // location / weight of chunk i+1's sample are already in flight (requested in phase A of
-    // chunk i) and so are the grad_output rows of chunk i+1's queries (requested in phase B
-    // of chunk i, once their indices are visible in s_q).  s_q[parity] of chunk i+1 is written
-    // in phase B of chunk i: by then (barrier 1) nobody reads chunk i-1's copy any more.
-    const int ql = tid >> 2, p = tid & 3;
-    const int gslot = tid >> 3, gsub = tid & 7;          // grad_output rows: slots gslot, gslot+64
+    auto advance = [&]() {
+      if (++e.phx == e.SX) {
+        e.phx = 0;
+        if (++e.phy == e.SY) load_level(e.lq + 1);
+      }
+    };
+    // Per-chunk uniforms of the chunk being consumed (phase E maps a slot back to its query).
+    int c_qorg = 0, c_SX = 0, c_SYW = 0;
+    // Software pipeline: the next chunk's sample (location, weight) and grad_output rows are
+    // requested during phase A of the current chunk and consumed one chunk later.
     bool n_valid = false;
-    int n_lq = 0, n_yq = 0, n_xq = 0;
-    uint32_t n_s = 0, n_q = 0;
+    float n_cx = 0.f, n_cy = 0.f;
+    uint32_t n_s = 0;
     float2 n_xy = make_float2(0.f, 0.f);
     float n_a = 0.f;
     float4 n_g0 = make_float4(0.f, 0.f, 0.f, 0.f), n_g1 = n_g0;
-    auto prefetch_sample = [&](int c0) {
-      n_valid = c0 + ql < NC;
+    int n_qorg = 0, n_SX = 0, n_SYW = 0;
+    auto prefetch = [&]() {                               // for the chunk `e` points at
+      const int vx = e.nx - e.phx, vy = e.ny - e.phy;     // slot (i, j) valid iff SX*i < vx, SY*j < vy
+      n_SX = e.SX;
+      n_SYW = e.SY * e.Wq;
+      n_qorg = e.qoff + (e.cy0 + e.phy) * e.Wq + e.cx0 + e.phx;
+      n_valid = e.SX * qi < vx && e.SY * qj < vy;
       if (n_valid) {
-        const uint32_t q = decode(c0 + ql, n_lq, n_yq, n_xq);
-        n_q = q;
+        const uint32_t q = (uint32_t)(n_qorg + qj * n_SYW + qi * n_SX);
+        n_cx = nominal_centre(e.cx0 + e.phx + e.SX * qi, e.sx);
+        n_cy = nominal_centre(e.cy0 + e.phy + e.SY * qj, e.sy);
         const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
         n_s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (uint32_t)p;
         n_xy = *reinterpret_cast<const float2 *>(loc + 2u * n_s);
         n_a = aw[n_s];
       }
+      const int gi = gslot & (LATX - 1), gj = gslot / LATX;
+      if (e.SX * gi < vx && e.SY * gj < vy)
+        n_g0 = ld16(grad_out, (((uint32_t)n * Lq + (uint32_t)(n_qorg + gj * n_SYW + gi * n_SX)) *
+                                   (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
+      if (e.SX * gi < vx && e.SY * (gj + 64 / LATX) < vy)
+        n_g1 = ld16(grad_out, (((uint32_t)n * Lq +
+                                (uint32_t)(n_qorg + (gj + 64 / LATX) * n_SYW + gi * n_SX)) *
+                                   (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
     };
-    auto prefetch_rows = [&](int c0, int buf) {
-      if (c0 + gslot < NC)
-        n_g0 = ld16(grad_out, (((uint32_t)n * Lq + s_q[buf * CQ + gslot]) * (uint32_t)M +
-                               (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
-      if (c0 + gslot + 64 < NC)
-        n_g1 = ld16(grad_out, (((uint32_t)n * Lq + s_q[buf * CQ + gslot + 64]) * (uint32_t)M +
-                               (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
-    };
-    if (NC > 0) {
-      prefetch_sample(0);
-      if (n_valid && p == 0) s_q[ql] = n_q;
+    load_level(0);
+    bool have = e.lq < L;                                 // a chunk has been prefetched
+    if (have) {
+      prefetch();
+      advance();
     }
     MSDA_STAMP(0)   // item setup: value tile, candidate rectangles, first prefetch
 
-    for (int c0 = 0, chunk = 0; c0 < NC; c0 += CQ, ++chunk) {
+    for (int chunk = 0; have; ++chunk) {
       // ---------------- phase A: examine one candidate sample per thread ----------------
-      const int qbuf = chunk & 1, qnext = qbuf ^ 1;      // s_q / s_hcount parity of this chunk
-      const int hbuf = qbuf;
+      const int par = chunk & 1;
       bool own1 = false, own2 = false, own3 = false, own4 = false, home = false;
-      uint32_t pos1 = 0, pos2 = 0, pos3 = 0, pos4 = 0;
       int r1 = 0;
       float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
       float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 g0 = n_g0, g1 = n_g1;                 // this chunk's grad_output rows
+      c_qorg = n_qorg;
+      c_SX = n_SX;
+      c_SYW = n_SYW;
       if (n_valid) {
         const uint32_t s = n_s;
         const float a = n_a;
-        const int lq = n_lq, yq = n_yq, xq = n_xq;
         const Corner4<float> g = corner_setup<float>(n_xy.x, n_xy.y, H, W);
-        const float cx = nominal_centre(xq, s_sx[lq]), cy = nominal_centre(yq, s_sy[lq]);
+        const float cx = n_cx, cy = n_cy;
         if (!g.in) {
           // gate closed: zero gradients, written by the tile holding the nominal centre
           const int px = min(max((int)floorf(cx + 0.5f), 0), W - 1) - x0;
@@ -563,10 +596,6 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           own3 = g.ok3 && yin1 && xin0;
           own4 = g.ok4 && yin1 && xin1;
           r1 = ly0 * T + lx0;
-          if (own1) pos1 = atomicAdd(&s_hist[r1], 1u);
-          if (own2) pos2 = atomicAdd(&s_hist[r1 + 1], 1u);
-          if (own3) pos3 = atomicAdd(&s_hist[r1 + T], 1u);
-          if (own4) pos4 = atomicAdd(&s_hist[r1 + T + 1], 1u);
           w1 = g.k1 * a;
           w2 = g.k2 * a;
           w3 = g.k3 * a;
@@ -582,49 +611,57 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           }
         }
       }
-      const bool more = c0 + CQ < NC;
-      if (more) prefetch_sample(c0 + CQ);
+      // Bucket positions: four unconditional, independent LDS atomics (corners the tile does
+      // not own count into a per-lane dummy), so their latencies overlap.
+      const int dummy = TP + (tid & 63);
+      const uint32_t pos1 = atomicAdd(&s_cnt[par][own1 ? r1 : dummy], 1u);
+      const uint32_t pos2 = atomicAdd(&s_cnt[par][own2 ? r1 + 1 : dummy], 1u);
+      const uint32_t pos3 = atomicAdd(&s_cnt[par][own3 ? r1 + T : dummy], 1u);
+      const uint32_t pos4 = atomicAdd(&s_cnt[par][own4 ? r1 + T + 1 : dummy], 1u);
+      have = e.lq < L;
+      if (have) {
+        prefetch();
+        advance();
+      }
+      {
+        const uint32_t top = max(max(own1 ? pos1 : 0u, own2 ? pos2 : 0u),
+                                 max(own3 ? pos3 : 0u, own4 ? pos4 : 0u));
+        if (top >= (uint32_t)KB) atomicMax(&s_max[par], top);   // rare: a bucket overflowed
+      }
       MSDA_STAMP(1)   // phase A
       __syncthreads();   // every wave is past phases D/E of the previous chunk
       MSDA_STAMP(2)   // barrier 1
-      // ------- phase B: grad_output rows -> LDS, next rows requested, prefix sum (wave 0) -------
-      if (chunk == 0) prefetch_rows(c0, qbuf);           // first chunk of an item: not in flight yet
-      s_go[gslot * 8 + (gsub ^ (gslot & 7))] = n_g0;
-      s_go[(gslot + 64) * 8 + (gsub ^ ((gslot + 64) & 7))] = n_g1;
-      if (more && n_valid && p == 0) s_q[qnext * CQ + ql] = n_q;
-      if (tid < 64) {
-        const uint4 c = reinterpret_cast<uint4 *>(s_hist)[tid];
-        const uint32_t sum = c.x + c.y + c.z + c.w;
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t t = __shfl_up(incl, off);
-          if (tid >= off) incl += t;
-        }
-        const uint32_t excl = incl - sum;
-        reinterpret_cast<uint4 *>(s_base)[tid] =
-            make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
-        if (tid == 63) s_base[TP] = incl;
-        reinterpret_cast<uint4 *>(s_hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid == 0) s_hcount[hbuf ^ 1] = 0u;           // the next chunk's home counter
+      // ---------------- phase C: contributions -> pixel buckets; rows, home list -> LDS ----------------
+      s_go[gslot * 8 + (gsub ^ (gslot & 7))] = g0;
+      s_go[(gslot + 64) * 8 + (gsub ^ ((gslot + 64) & 7))] = g1;
+      if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
+      for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
+      if (tid == 0) {
+        s_hcount[par ^ 1] = 0u;
+        s_max[par ^ 1] = 0u;
       }
-      __syncthreads();
-      MSDA_STAMP(3)   // phase B + barrier 2
-      // ---------------- phase C: scatter contributions into pixel order ----------------
-      if (own1) s_rec[s_base[r1] + pos1] = make_uint2((uint32_t)ql, __float_as_uint(w1));
-      if (own2) s_rec[s_base[r1 + 1] + pos2] = make_uint2((uint32_t)ql, __float_as_uint(w2));
-      if (own3) s_rec[s_base[r1 + T] + pos3] = make_uint2((uint32_t)ql, __float_as_uint(w3));
-      if (own4) s_rec[s_base[r1 + T + 1] + pos4] = make_uint2((uint32_t)ql, __float_as_uint(w4));
-      if (home) s_home[atomicAdd(&s_hcount[hbuf], 1u)] = hrec;
-      if (more) prefetch_rows(c0 + CQ, qnext);
-      __syncthreads();
-      MSDA_STAMP(4)   // phase C + barrier 3
-      // ---------------- phase D: every pixel's owners sum their list ----------------
-      {
+      const uint32_t rounds = s_max[par] / (uint32_t)KB + 1u;          // 1 unless a bucket overflowed
+      for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t lo = r * (uint32_t)KB;
+        if (r > 0) __syncthreads();                                     // previous round consumed
+        if (own1 && pos1 - lo < (uint32_t)KB)
+          s_rec[r1 * KB + (int)(pos1 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w1));
+        if (own2 && pos2 - lo < (uint32_t)KB)
+          s_rec[(r1 + 1) * KB + (int)(pos2 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w2));
+        if (own3 && pos3 - lo < (uint32_t)KB)
+          s_rec[(r1 + T) * KB + (int)(pos3 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w3));
+        if (own4 && pos4 - lo < (uint32_t)KB)
+          s_rec[(r1 + T + 1) * KB + (int)(pos4 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w4));
+        __syncthreads();
+        if (r == 0) {
+          MSDA_STAMP(4)   // phase C + barrier 2
+        }
+        // ---------------- phase D: every pixel's owners sum their bucket ----------------
         const int px = tid >> 1, half = tid & 1;
-        const uint32_t b0 = s_base[px], b1 = s_base[px + 1];
-        for (uint32_t i = b0; i < b1; ++i) {
-          const uint2 rc = s_rec[i];
+        const uint32_t cnt = s_cnt[par][px];
+        const int nrec = (int)min(cnt > lo ? cnt - lo : 0u, (uint32_t)KB);
+        for (int i = 0; i < nrec; ++i) {
+          const uint2 rc = s_rec[px * KB + i];
           const float w = __uint_as_float(rc.y);
           const int row = (int)rc.x;
 #pragma unroll
@@ -640,7 +677,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       MSDA_STAMP(5)   // phase D
       // ---------------- phase E: gradients of the samples this tile is home to ----------------
       {
-        const uint32_t hc = s_hcount[hbuf];
+        const uint32_t hc = s_hcount[par];
         const int sub = tid & 7;
         // all 8 lanes of a group share h, so a group is in or out of the loop together
         for (uint32_t h = (uint32_t)tid >> 3; h < hc; h += NT / 8) {
@@ -663,7 +700,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           const float d4 = sum8(g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w);
           if (sub == 0) {
             const float lh = hr.x, lw = hr.y, a = hr.z, hh = 1.f - lh, hw = 1.f - lw;
-            const uint32_t q = s_q[qbuf * CQ + slot];
+            const uint32_t q = (uint32_t)(c_qorg + (slot / LATX) * c_SYW + (slot & (LATX - 1)) * c_SX);
             const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
             const uint32_t s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (e & 3u);
             grad_aw[s] = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
