@@ -374,13 +374,15 @@ __device__ __forceinline__ bool is_near(const Corner4<float> &g, float cx, float
   return g.in && fabsf(g.w_im - cx) <= NEAR_R && fabsf(g.h_im - cy) <= NEAR_R;
 }
 
-// Sum over the 8 lanes of an aligned lane group, entirely in DPP (no LDS round trip):
-// xor-1 and xor-2 as quad permutes, then row_half_mirror brings in the other quad's total.
-__device__ __forceinline__ float sum8(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-  return v;
+// Workgroup-uniform values read from LDS land in VGPRs; pin them to scalar registers.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// Sum over an aligned lane pair (quad permute [1,0,3,2]), in DPP: no LDS round trip.
+__device__ __forceinline__ float sum2(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
 __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     s_ioff[L] = io;
   }
   __syncthreads();
-  const int total_items = s_ioff[L];
+  const int total_items = uni(s_ioff[L]);
   MSDA_STAMP_DECL
 
   const int ql = tid >> 2, p = tid & 3;                 // exam: query slot, point
@@ -426,10 +428,10 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
 
   for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
     int l = 0;
-    while (l + 1 < L && item >= s_ioff[l + 1]) ++l;
-    const int H = s_H[l], W = s_W[l];
+    while (l + 1 < L && item >= uni(s_ioff[l + 1])) ++l;
+    const int H = uni(s_H[l]), W = uni(s_W[l]);
     const int ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
-    const int rem = item - s_ioff[l];
+    const int rem = item - uni(s_ioff[l]);
     const int tile = rem % (ntx * nty), nm = rem / (ntx * nty);
     const int m = nm % M, n = nm / M;
     const int y0 = (tile / ntx) * T, x0 = (tile % ntx) * T;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     }
     // value tile -> LDS (zeros outside the level), counters cleared
     {
-      const uint32_t lrow = (uint32_t)n * (uint32_t)S + (uint32_t)s_lsi[l];
+      const uint32_t lrow = (uint32_t)n * (uint32_t)S + (uint32_t)uni(s_lsi[l]);
       for (int t = tid; t < (ZROW + 1) * 8; t += NT) {
         const int row = t >> 3, sub = t & 7;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -497,21 +499,21 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       float sx, sy;
     } e;
     auto load_level = [&](int lq) {
-      while (lq < L && s_cny[lq] == 0) ++lq;
+      while (lq < L && uni(s_cny[lq]) == 0) ++lq;
       e.lq = lq;
       e.phy = 0;
       e.phx = 0;
       if (lq < L) {
-        e.SX = s_SX[lq];
-        e.SY = s_SY[lq];
-        e.nx = s_cnx[lq];
-        e.ny = s_cny[lq];
-        e.cx0 = s_cx0[lq];
-        e.cy0 = s_cy0[lq];
-        e.Wq = s_W[lq];
-        e.qoff = s_qoff[lq];
-        e.sx = s_sx[lq];
-        e.sy = s_sy[lq];
+        e.SX = uni(s_SX[lq]);
+        e.SY = uni(s_SY[lq]);
+        e.nx = uni(s_cnx[lq]);
+        e.ny = uni(s_cny[lq]);
+        e.cx0 = uni(s_cx0[lq]);
+        e.cy0 = uni(s_cy0[lq]);
+        e.Wq = uni(s_W[lq]);
+        e.qoff = uni(s_qoff[lq]);
+        e.sx = unif(s_sx[lq]);
+        e.sy = unif(s_sy[lq]);
       }
     };
     auto advance = [&]() {
@@ -530,10 +532,11 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     float2 n_xy = make_float2(0.f, 0.f);
     float n_a = 0.f;
     float4 n_g0 = make_float4(0.f, 0.f, 0.f, 0.f), n_g1 = n_g0;
-    int n_qorg = 0, n_SX = 0, n_SYW = 0;
+    int n_qorg = 0, n_SX = 0, n_SY = 0, n_SYW = 0, n_vx = 0, n_vy = 0;
     auto prefetch = [&]() {                               // for the chunk `e` points at
       const int vx = e.nx - e.phx, vy = e.ny - e.phy;     // slot (i, j) valid iff SX*i < vx, SY*j < vy
       n_SX = e.SX;
+      n_SY = e.SY;
       n_SYW = e.SY * e.Wq;
       n_qorg = e.qoff + (e.cy0 + e.phy) * e.Wq + e.cx0 + e.phx;
       n_valid = e.SX * qi < vx && e.SY * qj < vy;
@@ -546,11 +549,17 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
         n_xy = *reinterpret_cast<const float2 *>(loc + 2u * n_s);
         n_a = aw[n_s];
       }
+      n_vx = vx;
+      n_vy = vy;
+    };
+    // grad_output rows of the chunk described by n_* (issued in phase C, once the previous
+    // rows have been handed to LDS, and consumed in phase C of the next chunk)
+    auto prefetch_rows = [&]() {
       const int gi = gslot & (LATX - 1), gj = gslot / LATX;
-      if (e.SX * gi < vx && e.SY * gj < vy)
+      if (n_SX * gi < n_vx && n_SY * gj < n_vy)
         n_g0 = ld16(grad_out, (((uint32_t)n * Lq + (uint32_t)(n_qorg + gj * n_SYW + gi * n_SX)) *
                                    (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
-      if (e.SX * gi < vx && e.SY * (gj + 64 / LATX) < vy)
+      if (n_SX * gi < n_vx && n_SY * (gj + 64 / LATX) < n_vy)
         n_g1 = ld16(grad_out, (((uint32_t)n * Lq +
                                 (uint32_t)(n_qorg + (gj + 64 / LATX) * n_SYW + gi * n_SX)) *
                                    (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
@@ -559,6 +568,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     bool have = e.lq < L;                                 // a chunk has been prefetched
     if (have) {
       prefetch();
+      prefetch_rows();
       advance();
     }
     MSDA_STAMP(0)   // item setup: value tile, candidate rectangles, first prefetch
@@ -570,7 +580,6 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       int r1 = 0;
       float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
       float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 g0 = n_g0, g1 = n_g1;                 // this chunk's grad_output rows
       c_qorg = n_qorg;
       c_SX = n_SX;
       c_SYW = n_SYW;
@@ -632,15 +641,16 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       __syncthreads();   // every wave is past phases D/E of the previous chunk
       MSDA_STAMP(2)   // barrier 1
       // ---------------- phase C: contributions -> pixel buckets; rows, home list -> LDS ----------------
-      s_go[gslot * 8 + (gsub ^ (gslot & 7))] = g0;
-      s_go[(gslot + 64) * 8 + (gsub ^ ((gslot + 64) & 7))] = g1;
+      s_go[gslot * 8 + (gsub ^ (gslot & 7))] = n_g0;
+      s_go[(gslot + 64) * 8 + (gsub ^ ((gslot + 64) & 7))] = n_g1;
+      if (have) prefetch_rows();                         // rows of the chunk after this one
       if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
       for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
       if (tid == 0) {
         s_hcount[par ^ 1] = 0u;
         s_max[par ^ 1] = 0u;
       }
-      const uint32_t rounds = s_max[par] / (uint32_t)KB + 1u;          // 1 unless a bucket overflowed
+      const uint32_t rounds = (uint32_t)uni((int)s_max[par]) / (uint32_t)KB + 1u;          // 1 unless a bucket overflowed
       for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t lo = r * (uint32_t)KB;
         if (r > 0) __syncthreads();                                     // previous round consumed
@@ -657,48 +667,62 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           MSDA_STAMP(4)   // phase C + barrier 2
         }
         // ---------------- phase D: every pixel's owners sum their bucket ----------------
+        // Two records per step (a record past the end of the list is a copy of slot 0 with
+        // weight 0), so eight row reads are in flight before the FMAs start.
         const int px = tid >> 1, half = tid & 1;
         const uint32_t cnt = s_cnt[par][px];
         const int nrec = (int)min(cnt > lo ? cnt - lo : 0u, (uint32_t)KB);
-        for (int i = 0; i < nrec; ++i) {
-          const uint2 rc = s_rec[px * KB + i];
-          const float w = __uint_as_float(rc.y);
-          const int row = (int)rc.x;
+        for (int i = 0; i < nrec; i += 2) {
+          const uint4 rr = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i]);
+          const bool two = i + 1 < nrec;
+          const int rowa = (int)rr.x, rowb = two ? (int)rr.z : 0;
+          const float wa = __uint_as_float(rr.y), wb = two ? __uint_as_float(rr.w) : 0.f;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float4 gv = s_go[row * 8 + ((half * 4 + k) ^ (row & 7))];
-            acc[k].x += w * gv.x;
-            acc[k].y += w * gv.y;
-            acc[k].z += w * gv.z;
-            acc[k].w += w * gv.w;
+            const float4 ga = s_go[rowa * 8 + ((half * 4 + k) ^ (rowa & 7))];
+            const float4 gb = s_go[rowb * 8 + ((half * 4 + k) ^ (rowb & 7))];
+            acc[k].x += wa * ga.x + wb * gb.x;
+            acc[k].y += wa * ga.y + wb * gb.y;
+            acc[k].z += wa * ga.z + wb * gb.z;
+            acc[k].w += wa * ga.w + wb * gb.w;
           }
         }
       }
       MSDA_STAMP(5)   // phase D
       // ---------------- phase E: gradients of the samples this tile is home to ----------------
+      // Two lanes per sample, 16 channels each: dot the staged grad_output row with the four
+      // corner rows of the LDS value tile, pair-sum with one DPP step, lane 0 finishes.
       {
-        const uint32_t hc = s_hcount[par];
-        const int sub = tid & 7;
-        // all 8 lanes of a group share h, so a group is in or out of the loop together
-        for (uint32_t h = (uint32_t)tid >> 3; h < hc; h += NT / 8) {
+        const uint32_t hc = (uint32_t)uni((int)s_hcount[par]);
+        const int half = tid & 1;
+        for (uint32_t h = (uint32_t)tid >> 1; h < hc; h += NT / 2) {
           const float4 hr = s_home[h];
           const uint32_t pk = __float_as_uint(hr.w);
           const int by = (int)(pk & 31u) - 1, bx = (int)((pk >> 5) & 31u) - 1;
           const uint32_t ok = (pk >> 10) & 15u, e = pk >> 14;
           const int slot = (int)(e >> 2);
-          const float4 g4 = s_go[slot * 8 + (sub ^ (slot & 7))];
           const int rb = by * VT + bx;
           const int ra = (ok & 1u) ? rb : ZROW, rbb = (ok & 2u) ? rb + 1 : ZROW;
           const int rc = (ok & 4u) ? rb + VT : ZROW, rd = (ok & 8u) ? rb + VT + 1 : ZROW;
-          const float4 v1 = s_vt[ra * 8 + (sub ^ (ra & 7))];
-          const float4 v2 = s_vt[rbb * 8 + (sub ^ (rbb & 7))];
-          const float4 v3 = s_vt[rc * 8 + (sub ^ (rc & 7))];
-          const float4 v4 = s_vt[rd * 8 + (sub ^ (rd & 7))];
-          const float d1 = sum8(g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w);
-          const float d2 = sum8(g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w);
-          const float d3 = sum8(g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w);
-          const float d4 = sum8(g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w);
-          if (sub == 0) {
+          float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = half * 4 + k;
+            const float4 g4 = s_go[slot * 8 + (c ^ (slot & 7))];
+            const float4 v1 = s_vt[ra * 8 + (c ^ (ra & 7))];
+            const float4 v2 = s_vt[rbb * 8 + (c ^ (rbb & 7))];
+            const float4 v3 = s_vt[rc * 8 + (c ^ (rc & 7))];
+            const float4 v4 = s_vt[rd * 8 + (c ^ (rd & 7))];
+            d1 += g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w;
+            d2 += g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w;
+            d3 += g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w;
+            d4 += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+          }
+          d1 = sum2(d1);
+          d2 = sum2(d2);
+          d3 = sum2(d3);
+          d4 = sum2(d4);
+          if (half == 0) {
             const float lh = hr.x, lw = hr.y, a = hr.z, hh = 1.f - lh, hw = 1.f - lw;
             const uint32_t q = (uint32_t)(c_qorg + (slot / LATX) * c_SYW + (slot & (LATX - 1)) * c_SX);
             const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
@@ -717,7 +741,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       const int px = tid >> 1, half = tid & 1;
       const int py = px / T, pxx = px % T;
       if (py < th && pxx < tw) {
-        const uint32_t rowi = (uint32_t)n * (uint32_t)S + (uint32_t)s_lsi[l] +
+        const uint32_t rowi = (uint32_t)n * (uint32_t)S + (uint32_t)uni(s_lsi[l]) +
                               (uint32_t)((y0 + py) * W + x0 + pxx);
         float4 *dst = reinterpret_cast<float4 *>(
             reinterpret_cast<char *>(grad_value) +
