@@ -342,9 +342,9 @@ namespace tiled {
 // backward, accumulated per wave and added to a device array that no kernel reads.
 #ifdef MSDA_PHASE_STAMPS
 __device__ unsigned long long g_phase_cycles[16];
-#define MSDA_STAMP_DECL unsigned long long st_last = clock64(), st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MSDA_STAMP_DECL unsigned long long st_last = clock64(), st_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define MSDA_STAMP(i) { const unsigned long long st_now = clock64(); st_ph[i] += st_now - st_last; st_last = st_now; }
-#define MSDA_STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], st_ph[i]); }
+#define MSDA_STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 12; ++i) atomicAdd(&g_phase_cycles[i], st_ph[i]); }
 #else
 #define MSDA_STAMP_DECL
 #define MSDA_STAMP(i)
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int L,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
-  __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile, 16-B chunks XOR-swizzled by row
-  __shared__ float4 s_go[CQ * 8];           // grad_output rows of this chunk's queries (swizzled)
+  __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
+  __shared__ float4 s_go[CQ * 8];           // grad_output rows of this chunk's queries
   __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (query slot, weight bits)
   __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
   __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
             v = ld16(value, ((lrow + (uint32_t)(y * W + x)) * (uint32_t)M + (uint32_t)m) * 128u +
                                 (uint32_t)sub * 16u);
         }
-        s_vt[row * 8 + (sub ^ (row & 7))] = v;
+        s_vt[row * 8 + sub] = v;
       }
       for (int t = tid; t < 2 * (TP + 64); t += NT) (&s_cnt[0][0])[t] = 0;
     }
@@ -580,6 +580,10 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       int r1 = 0;
       float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
       float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef MSDA_PHASE_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MSDA_STAMP(8)   // wait for the prefetched sample (and everything older)
+#endif
       c_qorg = n_qorg;
       c_SX = n_SX;
       c_SYW = n_SYW;
@@ -620,6 +624,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           }
         }
       }
+      MSDA_STAMP(9)   // phase A: geometry
       // Bucket positions: four unconditional, independent LDS atomics (corners the tile does
       // not own count into a per-lane dummy), so their latencies overlap.
       const int dummy = TP + (tid & 63);
@@ -627,6 +632,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       const uint32_t pos2 = atomicAdd(&s_cnt[par][own2 ? r1 + 1 : dummy], 1u);
       const uint32_t pos3 = atomicAdd(&s_cnt[par][own3 ? r1 + T : dummy], 1u);
       const uint32_t pos4 = atomicAdd(&s_cnt[par][own4 ? r1 + T + 1 : dummy], 1u);
+      MSDA_STAMP(10)  // phase A: atomics issue
       have = e.lq < L;
       if (have) {
         prefetch();
@@ -641,8 +647,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
       __syncthreads();   // every wave is past phases D/E of the previous chunk
       MSDA_STAMP(2)   // barrier 1
       // ---------------- phase C: contributions -> pixel buckets; rows, home list -> LDS ----------------
-      s_go[gslot * 8 + (gsub ^ (gslot & 7))] = n_g0;
-      s_go[(gslot + 64) * 8 + (gsub ^ ((gslot + 64) & 7))] = n_g1;
+      s_go[gslot * 8 + gsub] = n_g0;
+      s_go[(gslot + 64) * 8 + gsub] = n_g1;
       if (have) prefetch_rows();                         // rows of the chunk after this one
       if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
       for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
@@ -651,6 +657,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
         s_max[par ^ 1] = 0u;
       }
       const uint32_t rounds = (uint32_t)uni((int)s_max[par]) / (uint32_t)KB + 1u;          // 1 unless a bucket overflowed
+      MSDA_STAMP(3)   // phase C: rows to LDS, home push, zeroing, row prefetch
       for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t lo = r * (uint32_t)KB;
         if (r > 0) __syncthreads();                                     // previous round consumed
@@ -662,9 +669,12 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           s_rec[(r1 + T) * KB + (int)(pos3 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w3));
         if (own4 && pos4 - lo < (uint32_t)KB)
           s_rec[(r1 + T + 1) * KB + (int)(pos4 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w4));
+        if (r == 0) {
+          MSDA_STAMP(4)   // phase C: scatter
+        }
         __syncthreads();
         if (r == 0) {
-          MSDA_STAMP(4)   // phase C + barrier 2
+          MSDA_STAMP(7)   // barrier 2
         }
         // ---------------- phase D: every pixel's owners sum their bucket ----------------
         // Two records per step (a record past the end of the list is a copy of slot 0 with
@@ -679,8 +689,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           const float wa = __uint_as_float(rr.y), wb = two ? __uint_as_float(rr.w) : 0.f;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float4 ga = s_go[rowa * 8 + ((half * 4 + k) ^ (rowa & 7))];
-            const float4 gb = s_go[rowb * 8 + ((half * 4 + k) ^ (rowb & 7))];
+            const int c = half * 4 + ((k + px) & 3);     // this lane's k-th chunk (see flush)
+            const float4 ga = s_go[rowa * 8 + c];
+            const float4 gb = s_go[rowb * 8 + c];
             acc[k].x += wa * ga.x + wb * gb.x;
             acc[k].y += wa * ga.y + wb * gb.y;
             acc[k].z += wa * ga.z + wb * gb.z;
@@ -707,12 +718,12 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
           float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int c = half * 4 + k;
-            const float4 g4 = s_go[slot * 8 + (c ^ (slot & 7))];
-            const float4 v1 = s_vt[ra * 8 + (c ^ (ra & 7))];
-            const float4 v2 = s_vt[rbb * 8 + (c ^ (rbb & 7))];
-            const float4 v3 = s_vt[rc * 8 + (c ^ (rc & 7))];
-            const float4 v4 = s_vt[rd * 8 + (c ^ (rd & 7))];
+            const int c = half * 4 + ((k + (int)h) & 3);
+            const float4 g4 = s_go[slot * 8 + c];
+            const float4 v1 = s_vt[ra * 8 + c];
+            const float4 v2 = s_vt[rbb * 8 + c];
+            const float4 v3 = s_vt[rc * 8 + c];
+            const float4 v4 = s_vt[rd * 8 + c];
             d1 += g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w;
             d2 += g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w;
             d3 += g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w;
@@ -747,7 +758,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
             reinterpret_cast<char *>(grad_value) +
             ((size_t)(rowi * (uint32_t)M + (uint32_t)m) * 128u + (size_t)half * 64u));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dst[k] = acc[k];
+        for (int k = 0; k < 4; ++k) dst[(k + px) & 3] = acc[k];
       }
     }
     __syncthreads();
