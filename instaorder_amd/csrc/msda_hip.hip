@@ -769,9 +769,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
 
 // ---------------------------------------------------------------------------------------
 // Second pass of the tiled backward: samples that are in range but not *near* their
-// query's nominal centre (see above).  One lane examines one sample; the wave then takes
-// its far samples two at a time (one per half-wave, lane = channel) and treats them like
-// the generic kernel: hardware float atomics into grad_value (which the first pass has
+// query's nominal centre (see above).  One lane scans the L*4 samples of one pair (its
+// locations are 96 contiguous bytes); the wave then takes the far samples found two at a
+// time (one per half-wave, lane = channel) and treats them like the generic kernel: hardware float atomics into grad_value (which the first pass has
 // fully written by then -- same stream), shuffle-reduced grad_sampling_loc/grad_attn_weight.
 // Every sample is scanned (sampling_loc is re-read once); nothing to do when all are near.
 // ---------------------------------------------------------------------------------------
@@ -795,85 +795,84 @@ __global__ __launch_bounds__(256) void msda_bwd_far_kernel(
   }
   __syncthreads();
   const uint32_t Lq = (uint32_t)S;
-  const uint32_t nsamples = (uint32_t)N * Lq * (uint32_t)M * (uint32_t)L * 4u;
+  const uint32_t npairs = (uint32_t)N * Lq * (uint32_t)M;
   const uint32_t stride = gridDim.x * 256u;
-  const uint32_t nrounds = (nsamples + stride - 1u) / stride;
+  const uint32_t nrounds = (npairs + stride - 1u) / stride;
   for (uint32_t round = 0; round < nrounds; ++round) {
-    const uint32_t s = round * stride + blockIdx.x * 256u + (uint32_t)tid;
-    bool far = false;
-    uint32_t vrow = 0, pair = 0;
-    int W = 1, H = 1;
-    float a = 0.f;
-    Corner4<float> g = {};
-    uint32_t okbits = 0;
-    if (s < nsamples) {
-      const uint32_t t = s >> 2;
-      const int l = (int)(t % (uint32_t)L);
-      pair = t / (uint32_t)L;
-      const uint32_t m = pair % (uint32_t)M, nq = pair / (uint32_t)M;
-      const uint32_t q = nq % Lq, n = nq / Lq;
+    // ---- scan: one lane examines the L*4 samples of one pair; bit (l*4+p) of farmask = far ----
+    const uint32_t pair = round * stride + blockIdx.x * 256u + (uint32_t)tid;
+    uint32_t farmask = 0;
+    if (pair < npairs) {
+      const uint32_t q = (pair / (uint32_t)M) % Lq;
       int lq = 0;
       while (lq + 1 < L && (int)q >= s_qoff[lq + 1]) ++lq;
       const int Wq = s_W[lq], Hq = s_H[lq];
       const int qq = (int)q - s_qoff[lq];
-      const int yq = qq / Wq, xq = qq % Wq;
-      H = s_H[l];
-      W = s_W[l];
-      const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
-      g = corner_setup<float>(xy.x, xy.y, H, W);
-      const float cx = nominal_centre(xq, level_scale(W, Wq));
-      const float cy = nominal_centre(yq, level_scale(H, Hq));
-      far = g.in && !is_near(g, cx, cy);
-      if (far) a = aw[s];
-      okbits = (g.ok1 ? 1u : 0u) | (g.ok2 ? 2u : 0u) | (g.ok3 ? 4u : 0u) | (g.ok4 ? 8u : 0u);
-      vrow = (n * (uint32_t)S + (uint32_t)s_lsi[l]) * (uint32_t)M + m;   // row of pixel 0
-    }
-    unsigned long long mask = __ballot(far);
-    while (mask) {
-      const int sa = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      int sb = -1;
-      if (mask) {
-        sb = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
+      const int yq = qq / Wq, xq = qq - yq * Wq;
+      for (int l = 0; l < L; ++l) {
+        const int H = s_H[l], W = s_W[l];
+        const float cx = nominal_centre(xq, level_scale(W, Wq));
+        const float cy = nominal_centre(yq, level_scale(H, Hq));
+        const uint32_t s0 = (pair * (uint32_t)L + (uint32_t)l) * 4u;
+        const float4 xa = ld16(loc, s0 * 8u), xb = ld16(loc, s0 * 8u + 16u);
+        const float lx[4] = {xa.x, xa.z, xb.x, xb.z}, ly[4] = {xa.y, xa.w, xb.y, xb.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float w_im = pix_coord(lx[p], (float)W), h_im = pix_coord(ly[p], (float)H);
+          const bool in = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+          const bool near = fabsf(w_im - cx) <= NEAR_R && fabsf(h_im - cy) <= NEAR_R;
+          if (in && !near) farmask |= 1u << (l * 4 + p);
+        }
       }
-      const bool act = lane < 32 || sb >= 0;
-      const int src = (lane < 32 || sb < 0) ? sa : sb;
-      const int ch = lane & 31;
-      const uint32_t s_s = __shfl(s, src), pair_s = __shfl(pair, src), vrow_s = __shfl(vrow, src);
-      const int W_s = __shfl(W, src), H_s = __shfl(H, src);
-      const float a_s = __shfl(a, src), lh = __shfl(g.lh, src), lw = __shfl(g.lw, src);
-      const float k1 = __shfl(g.k1, src), k2 = __shfl(g.k2, src), k3 = __shfl(g.k3, src),
-                  k4 = __shfl(g.k4, src);
-      const int o1 = __shfl(g.o1, src), o2 = __shfl(g.o2, src), o3 = __shfl(g.o3, src),
-                o4 = __shfl(g.o4, src);
-      const uint32_t ok = __shfl(okbits, src);
-      const float hh = 1.f - lh, hw = 1.f - lw;
+    }
+    // ---- process: far samples two at a time, one per half-wave, lane = channel ----
+    // The lower half takes the first (lane, bit) still pending, the upper half the last one.
+    for (;;) {
+      const unsigned long long pending = __ballot(farmask != 0u);
+      if (!pending) break;
+      const int la = __ffsll((long long)pending) - 1;
+      const int lb = 63 - __clzll((long long)pending);
+      const uint32_t ma = __shfl(farmask, la), mb = __shfl(farmask, lb);
+      const int ba = __ffs((int)ma) - 1, bb = 31 - __clz((int)mb);
+      const bool single = (la == lb) && (ba == bb);
+      if (lane == la) farmask &= ~(1u << ba);
+      if (lane == lb) farmask &= ~(1u << bb);
+      const bool upper = lane >= 32;
+      const bool act = !upper || !single;
+      const int src = upper ? lb : la, bit = upper ? bb : ba;
+      const uint32_t pr = __shfl(pair, src);
+      const int l = bit >> 2, ch = lane & 31;
+      const uint32_t s = (pr * (uint32_t)L + (uint32_t)l) * 4u + (uint32_t)(bit & 3);
+      const int H = s_H[l], W = s_W[l];
       float ga = 0.f, gw = 0.f, gh = 0.f;
       if (act) {
+        const uint32_t m = pr % (uint32_t)M, n = (pr / (uint32_t)M) / Lq;
+        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
+        const float a = aw[s];
+        const Corner4<float> g = corner_setup<float>(xy.x, xy.y, H, W);
         const uint32_t rowf = (uint32_t)M * 32u;
-        const float tg = grad_out[pair_s * 32u + (uint32_t)ch], tgv = tg * a_s;
-        const uint32_t base = vrow_s * 32u + (uint32_t)ch;
+        const uint32_t base = ((n * (uint32_t)S + (uint32_t)s_lsi[l]) * (uint32_t)M + m) * 32u + (uint32_t)ch;
+        const float tg = grad_out[pr * 32u + (uint32_t)ch], tgv = tg * a;
         // an in-level corner takes part even when its weight is exactly 0 (its value still
         // enters d/d loc); out-of-level corners read as 0 and scatter nothing
-        const float v1 = (ok & 1u) ? value[base + (uint32_t)o1 * rowf] : 0.f;
-        const float v2 = (ok & 2u) ? value[base + (uint32_t)o2 * rowf] : 0.f;
-        const float v3 = (ok & 4u) ? value[base + (uint32_t)o3 * rowf] : 0.f;
-        const float v4 = (ok & 8u) ? value[base + (uint32_t)o4 * rowf] : 0.f;
-        if (ok & 1u) atomicAdd(grad_value + base + (uint32_t)o1 * rowf, k1 * tgv);
-        if (ok & 2u) atomicAdd(grad_value + base + (uint32_t)o2 * rowf, k2 * tgv);
-        if (ok & 4u) atomicAdd(grad_value + base + (uint32_t)o3 * rowf, k3 * tgv);
-        if (ok & 8u) atomicAdd(grad_value + base + (uint32_t)o4 * rowf, k4 * tgv);
-        ga = tg * (k1 * v1 + k2 * v2 + k3 * v3 + k4 * v4);
-        gw = tgv * (hh * (v2 - v1) + lh * (v4 - v3));
-        gh = tgv * (hw * (v3 - v1) + lw * (v4 - v2));
+        const float v1 = g.ok1 ? value[base + (uint32_t)g.o1 * rowf] : 0.f;
+        const float v2 = g.ok2 ? value[base + (uint32_t)g.o2 * rowf] : 0.f;
+        const float v3 = g.ok3 ? value[base + (uint32_t)g.o3 * rowf] : 0.f;
+        const float v4 = g.ok4 ? value[base + (uint32_t)g.o4 * rowf] : 0.f;
+        if (g.ok1) atomicAdd(grad_value + base + (uint32_t)g.o1 * rowf, g.k1 * tgv);
+        if (g.ok2) atomicAdd(grad_value + base + (uint32_t)g.o2 * rowf, g.k2 * tgv);
+        if (g.ok3) atomicAdd(grad_value + base + (uint32_t)g.o3 * rowf, g.k3 * tgv);
+        if (g.ok4) atomicAdd(grad_value + base + (uint32_t)g.o4 * rowf, g.k4 * tgv);
+        ga = tg * (g.k1 * v1 + g.k2 * v2 + g.k3 * v3 + g.k4 * v4);
+        gw = tgv * (g.hh * (v2 - v1) + g.lh * (v4 - v3));
+        gh = tgv * (g.hw * (v3 - v1) + g.lw * (v4 - v2));
       }
       ga = group_sum<float, 32>(ga);
       gw = group_sum<float, 32>(gw);
       gh = group_sum<float, 32>(gh);
       if (act && ch == 0) {
-        grad_aw[s_s] = ga;
-        *reinterpret_cast<float2 *>(grad_loc + 2u * s_s) = make_float2((float)W_s * gw, (float)H_s * gh);
+        grad_aw[s] = ga;
+        *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2((float)W * gw, (float)H * gh);
       }
     }
   }
