@@ -84,14 +84,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist_on = world > 1
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     import MultiScaleDeformableAttention as MSDA
+    from instaorder_amd import distributed as D
     from instaorder_amd import ext, synthetic
+    D.init("nccl")            # no-op for one rank; RCCL process group otherwise
+    dist_on = world > 1
 
     batch, image = WORKLOADS[args.workload]
     shapes = synthetic.encoder_shapes(image)
@@ -105,10 +102,7 @@ def main():
         grads = MSDA.ms_deform_attn_backward(v, ss, lsi, loc, aw, go, 128)
         return out, grads
 
-    def barrier():
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = D.barrier       # rendezvous of the ranks + torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -120,10 +114,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert ext.launch_count() >= launches0 + 2 * args.steps, "HIP path did not run"
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed)
 
     # Per-kernel durations with HIP events on the stream the kernels are launched on
     # (torch's current stream), separate from the wall-clock region above.
@@ -142,8 +133,7 @@ def main():
     bwd_avg = sum(bwd_ms) / len(bwd_ms)
 
     if rank != 0:
-        if dist_on:
-            dist.destroy_process_group()
+        D.shutdown()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -197,8 +187,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(shapes, args.dist, args.cpu_images, args.cpu_reps)
     print(json.dumps(result), flush=True)
-    if dist_on:
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

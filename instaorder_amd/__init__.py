@@ -3,8 +3,12 @@ hot path of SNU-VGILab/InstaOrder (Mask2Former's MSDeformAttnPixelDecoder encode
 
   csrc/msda_hip.hip   hand-written HIP kernels (gfx950) + the C ABI (include/msda_hip.h)
   ext.py              host side of the extension boundary (checks, allocation, stream)
-  functions.py        MSDeformAttnFunction (autograd wrapper), as ops/functions in the reference
+  functions.py        MSDeformAttnFunction (autograd wrapper) + the CPU-tensor PyTorch path
+  modules.py          MSDeformAttn (the nn.Module that calls the op)
+  encoder.py          the pixel decoder's MSDA encoder stack, detectron2-free
+  synthetic.py        synthetic inputs of the encoder's shape (bench, tests)
 """
-from .functions import MSDeformAttnFunction
+from .functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
+from .modules import MSDeformAttn
 
-__all__ = ["MSDeformAttnFunction"]
+__all__ = ["MSDeformAttnFunction", "MSDeformAttn", "ms_deform_attn_core_pytorch"]

@@ -33,3 +33,29 @@ class MSDeformAttnFunction(Function):
             value, shapes, level_start, sampling_locations, attention_weights,
             grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
+    """CPU-tensor path of the reference's ops/functions module (ms_deform_attn_func.py:52-72):
+    per level, bilinear ``grid_sample`` (zero padding, align_corners=False) of the level's map
+    viewed as [N*M, D, H, W] at ``2*loc - 1``, then the attention-weighted sum over L*P.
+
+    The reference reaches it for CPU inputs through the bare ``except`` of MSDeformAttn.forward
+    (ops/modules/ms_deform_attn.py:116-121; BASELINE.json configs[0]).  Here it is selected by
+    device, never by catching an error: GPU tensors always take the HIP kernels."""
+    import torch
+    import torch.nn.functional as F
+    n, _, m, d = value.shape
+    lq, nl, npts = sampling_locations.shape[1], sampling_locations.shape[3], sampling_locations.shape[4]
+    sizes = [(int(h), int(w)) for h, w in value_spatial_shapes]
+    levels = value.split([h * w for h, w in sizes], dim=1)
+    grids = 2 * sampling_locations - 1
+    per_level = []
+    for lvl, (h, w) in enumerate(sizes):
+        fmap = levels[lvl].flatten(2).transpose(1, 2).reshape(n * m, d, h, w)
+        grid = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)
+        per_level.append(F.grid_sample(fmap, grid, mode="bilinear", padding_mode="zeros",
+                                       align_corners=False))
+    weights = attention_weights.transpose(1, 2).reshape(n * m, 1, lq, nl * npts)
+    out = (torch.stack(per_level, dim=-2).flatten(-2) * weights).sum(-1).view(n, m * d, lq)
+    return out.transpose(1, 2).contiguous()

@@ -215,3 +215,52 @@ def test_full_size_image_vs_oracle(msda, oracle):
     from instaorder_amd import synthetic
     inp = synthetic.make_inputs(1, synthetic.encoder_shapes(1024), dist="model", seed=2)
     _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
+
+
+def test_module_gpu_matches_reference_golden(msda):
+    """MSDeformAttn module (row a11/f1) on the GPU: HIP op inside, fp32, vs the reference
+    module's fp64 golden output and input gradients."""
+    from instaorder_amd import MSDeformAttn, ext
+    mc = cases.make_module_case()
+    g = load_golden("module_msdeformattn")
+    mod = MSDeformAttn(mc["d_model"], mc["n_levels"], mc["n_heads"], mc["n_points"]).cuda()
+    mod.load_state_dict({k: torch.from_numpy(v).float() for k, v in mc["state_dict"].items()})
+    t = lambda k: torch.from_numpy(mc[k]).float().cuda()
+    query, src = t("query").requires_grad_(True), t("src").requires_grad_(True)
+    before = ext.launch_count()
+    out = mod(query, t("ref"), src, torch.from_numpy(mc["shapes"]).cuda(),
+              torch.from_numpy(mc["lsi"]).cuda(), torch.from_numpy(mc["padding_mask"]).cuda())
+    up = torch.from_numpy(np.random.RandomState(202).standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+    out.backward(up)
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 2
+    assert rel_err(out.detach().cpu().numpy(), g["out"]) < 2e-5       # fp32 linears around the op
+    assert rel_err(query.grad.cpu().numpy(), g["grad_query"]) < 1e-4
+    assert rel_err(src.grad.cpu().numpy(), g["grad_src"]) < 1e-4
+
+
+def test_encoder_stack_gpu_runs_hip_path(msda):
+    """The 6-layer encoder stack at a small encoder shape: every layer's op goes through HIP
+    (6 forward launches; backward launches for the layers whose inputs need gradients)."""
+    from instaorder_amd import ext
+    from instaorder_amd.encoder import MSDeformAttnTransformerEncoderOnly, PositionEmbeddingSine
+    torch.manual_seed(0)
+    enc = MSDeformAttnTransformerEncoderOnly(d_model=256, nhead=8, num_encoder_layers=6,
+                                             dim_feedforward=256, dropout=0.0, num_feature_levels=3,
+                                             use_adapters=True).cuda()
+    pe = PositionEmbeddingSine(128, normalize=True)
+    srcs = [torch.randn(2, 256, h, w, device="cuda") for h, w in [(4, 4), (8, 8), (16, 16)]]
+    before = ext.launch_count()
+    memory, shapes, lsi = enc(srcs, [pe(x) for x in srcs])
+    memory.pow(2).mean().backward()
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 6 + 6
+    assert torch.isfinite(memory).all()
+    assert all(torch.isfinite(p.grad).all() for p in enc.parameters() if p.grad is not None)
+    # same weights on the CPU (PyTorch path) give the same memory
+    cpu = MSDeformAttnTransformerEncoderOnly(d_model=256, nhead=8, num_encoder_layers=6,
+                                             dim_feedforward=256, dropout=0.0, num_feature_levels=3,
+                                             use_adapters=True)
+    cpu.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+    ref, _, _ = cpu([x.cpu() for x in srcs], [pe(x.cpu()) for x in srcs])
+    assert rel_err(memory.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
