@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--dist", default="model", choices=["model", "uniform"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: value/output/grad_output in bf16, everything else fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -95,6 +97,8 @@ def main():
     inp = synthetic.make_inputs(batch, shapes, dist=args.dist, seed=rank, device="cuda")
     v, ss, lsi = inp["value"], inp["spatial_shapes"], inp["level_start_index"]
     loc, aw, go = inp["sampling_locations"], inp["attention_weights"], inp["grad_output"]
+    if args.dtype == "bf16":
+        v, go = v.to(torch.bfloat16), go.to(torch.bfloat16)
     samples = synthetic.num_samples(batch, shapes)
 
     def step():
@@ -139,7 +143,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     total_samples = samples * world
     value = total_samples / (elapsed / args.steps) / 1e9
-    fwd_b, bwd_b = synthetic.algorithmic_bytes_per_sample()
+    if args.dtype == "bf16":      # grad_value is returned in fp32: 22.67 + 45.33 = 68.00 B/sample
+        fwd_b = synthetic.algorithmic_bytes_per_sample(value_bytes=2)[0]
+        bwd_b = (32 * 2 + 32 * 2 + 32 * 4) / 12 + 24
+    else:
+        fwd_b, bwd_b = synthetic.algorithmic_bytes_per_sample()
     # dominant kernel = the backward call: msda_bwd_tiled_kernel (>90 % of it) followed by
     # msda_bwd_far_kernel on the same stream; both are inside the event bracket
     bwd_gbs = samples * bwd_b / (bwd_avg * 1e-3) / 1e9
@@ -164,7 +172,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": "%s: MSDeformAttn fwd+bwd, bs=%d/GPU, %d^2 input, levels %s, "
                                "M=8, D=32, P=4, Lq=S=%d, %s locations"

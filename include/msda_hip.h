@@ -83,6 +83,28 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
                       int num_query, int num_point, double *grad_value,
                       double *grad_sampling_loc, double *grad_attn_weight, void *stream);
 
+/*
+ * bf16 variant (BASELINE.json configs[2]; not reference behaviour: the reference dispatches
+ * float/double only, src/cuda/ms_deform_attn_cuda.cu:69,139, and its caller forces fp32,
+ * pixel_decoder/msdeformattn.py:435-441).  value / output / grad_output are bfloat16 bit
+ * patterns (uint16_t); sampling locations, attention weights and ALL THREE gradients are fp32;
+ * accumulation is fp32.  grad_value comes back in fp32 (algorithmic bytes 68.00 B/sample, not
+ * 62.67).  Forward needs channels == 32; backward needs the encoder shape (channels == 32,
+ * num_point == 4, num_query == spatial_size).  Same kernels as the fp32 fast paths.
+ */
+int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const float *sampling_loc,
+                      const float *attn_weight, int batch, int spatial_size, int num_heads,
+                      int channels, int num_levels, int num_query, int num_point,
+                      uint16_t *output, void *stream);
+
+int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                       const int64_t *level_start_index, const float *sampling_loc,
+                       const float *attn_weight, const uint16_t *grad_output, int batch,
+                       int spatial_size, int num_heads, int channels, int num_levels,
+                       int num_query, int num_point, float *grad_value,
+                       float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,9 +120,42 @@ __device__ __forceinline__ float4 ld16(const float *__restrict__ base, uint32_t 
   return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
+// bf16 storage (value / output / grad_output of the bf16 variant); arithmetic stays fp32.
+struct bf16_t {
+  uint16_t bits;
+};
+__device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {      // round to nearest even
+  const uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // keep a NaN a NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// Four consecutive channels of a row.  `f32_off` is the byte offset the element would have in
+// an fp32 tensor (4 * element index), so all index arithmetic is shared between the types.
+__device__ __forceinline__ float4 ldrow4(const float *__restrict__ base, uint32_t f32_off) {
+  return ld16(base, f32_off);
+}
+__device__ __forceinline__ float4 ldrow4(const bf16_t *__restrict__ base, uint32_t f32_off) {
+  const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + (f32_off >> 1));
+  return make_float4(bf16_to_f32(r.x & 0xffffu), bf16_to_f32(r.x >> 16), bf16_to_f32(r.y & 0xffffu),
+                     bf16_to_f32(r.y >> 16));
+}
+__device__ __forceinline__ void strow4(float *__restrict__ base, uint32_t f32_off, float4 v) {
+  *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + f32_off) = v;
+}
+__device__ __forceinline__ void strow4(bf16_t *__restrict__ base, uint32_t f32_off, float4 v) {
+  *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(base) + (f32_off >> 1)) =
+      make_uint2(f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16), f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16));
+}
+__device__ __forceinline__ float ldval(const float *__restrict__ base, uint32_t idx) { return base[idx]; }
+__device__ __forceinline__ float ldval(const bf16_t *__restrict__ base, uint32_t idx) {
+  return bf16_to_f32(base[idx].bits);
+}
+
 // NS samples of one level: all 4*NS corner rows are requested before the first is used.
-template <int NS>
-__device__ __forceinline__ void fwd_samples_d32(const float *__restrict__ value, uint32_t lbyte,
+template <typename VT, int NS>
+__device__ __forceinline__ void fwd_samples_d32(const VT *__restrict__ value, uint32_t lbyte,
                                                 uint32_t row_bytes, int H, int W,
                                                 const float (&lx)[NS], const float (&ly)[NS],
                                                 const float (&a)[NS], float4 &acc) {
@@ -135,10 +168,10 @@ __device__ __forceinline__ void fwd_samples_d32(const float *__restrict__ value,
     k[i][1] = c.k2 * a[i];
     k[i][2] = c.k3 * a[i];
     k[i][3] = c.k4 * a[i];
-    v[i][0] = ld16(value, lbyte + (uint32_t)c.o1 * row_bytes);
-    v[i][1] = ld16(value, lbyte + (uint32_t)c.o2 * row_bytes);
-    v[i][2] = ld16(value, lbyte + (uint32_t)c.o3 * row_bytes);
-    v[i][3] = ld16(value, lbyte + (uint32_t)c.o4 * row_bytes);
+    v[i][0] = ldrow4(value, lbyte + (uint32_t)c.o1 * row_bytes);
+    v[i][1] = ldrow4(value, lbyte + (uint32_t)c.o2 * row_bytes);
+    v[i][2] = ldrow4(value, lbyte + (uint32_t)c.o3 * row_bytes);
+    v[i][3] = ldrow4(value, lbyte + (uint32_t)c.o4 * row_bytes);
   }
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -152,12 +185,12 @@ __device__ __forceinline__ void fwd_samples_d32(const float *__restrict__ value,
   }
 }
 
-template <bool P4>
-__global__ __launch_bounds__(256) void msda_fwd_f32_d32_kernel(
-    const float *__restrict__ value, const int64_t *__restrict__ shapes,
+template <typename VT, bool P4>
+__global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ aw, int S, int M, int L, int Lq, int P, uint32_t npairs,
-    uint32_t nblocks, float *__restrict__ out) {
+    uint32_t nblocks, VT *__restrict__ out) {
   const uint32_t blk = xcd_remap(blockIdx.x, nblocks);
   const uint32_t pair = blk * 32u + (threadIdx.x >> 3);
   if (pair >= npairs) return;
@@ -179,16 +212,16 @@ __global__ __launch_bounds__(256) void msda_fwd_f32_d32_kernel(
       const float lx[4] = {xa.x, xa.z, xb.x, xb.z};
       const float ly[4] = {xa.y, xa.w, xb.y, xb.w};
       const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-      fwd_samples_d32<4>(value, lbyte, row_bytes, H, W, lx, ly, a, acc);
+      fwd_samples_d32<VT, 4>(value, lbyte, row_bytes, H, W, lx, ly, a, acc);
     } else {
       for (int p = 0; p < P; ++p) {
         const uint32_t s = sbase + (uint32_t)(l * P + p);
         const float lx[1] = {loc[2u * s]}, ly[1] = {loc[2u * s + 1u]}, a[1] = {aw[s]};
-        fwd_samples_d32<1>(value, lbyte, row_bytes, H, W, lx, ly, a, acc);
+        fwd_samples_d32<VT, 1>(value, lbyte, row_bytes, H, W, lx, ly, a, acc);
       }
     }
   }
-  *reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (pair * 128u + sub * 16u)) = acc;
+  strow4(out, pair * 128u + sub * 16u, acc);
 }
 
 // =======================================================================================
@@ -385,8 +418,9 @@ __device__ __forceinline__ float sum2(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
+template <typename ST>   // ST: storage type of value / grad_output (float or bf16_t)
 __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
-    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const ST *__restrict__ grad_out, const ST *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int L,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
@@ -478,7 +512,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
         if (row < ZROW) {
           const int y = y0 + row / VT, x = x0 + row % VT;
           if (y < H && x < W)
-            v = ld16(value, ((lrow + (uint32_t)(y * W + x)) * (uint32_t)M + (uint32_t)m) * 128u +
+            v = ldrow4(value, ((lrow + (uint32_t)(y * W + x)) * (uint32_t)M + (uint32_t)m) * 128u +
                                 (uint32_t)sub * 16u);
         }
         s_vt[row * 8 + sub] = v;
@@ -557,10 +591,10 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
     auto prefetch_rows = [&]() {
       const int gi = gslot & (LATX - 1), gj = gslot / LATX;
       if (n_SX * gi < n_vx && n_SY * gj < n_vy)
-        n_g0 = ld16(grad_out, (((uint32_t)n * Lq + (uint32_t)(n_qorg + gj * n_SYW + gi * n_SX)) *
+        n_g0 = ldrow4(grad_out, (((uint32_t)n * Lq + (uint32_t)(n_qorg + gj * n_SYW + gi * n_SX)) *
                                    (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
       if (n_SX * gi < n_vx && n_SY * (gj + 64 / LATX) < n_vy)
-        n_g1 = ld16(grad_out, (((uint32_t)n * Lq +
+        n_g1 = ldrow4(grad_out, (((uint32_t)n * Lq +
                                 (uint32_t)(n_qorg + (gj + 64 / LATX) * n_SYW + gi * n_SX)) *
                                    (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
     };
@@ -775,8 +809,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
 // fully written by then -- same stream), shuffle-reduced grad_sampling_loc/grad_attn_weight.
 // Every sample is scanned (sampling_loc is re-read once); nothing to do when all are near.
 // ---------------------------------------------------------------------------------------
+template <typename ST>
 __global__ __launch_bounds__(256) void msda_bwd_far_kernel(
-    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const ST *__restrict__ grad_out, const ST *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int L,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
@@ -852,13 +887,13 @@ __global__ __launch_bounds__(256) void msda_bwd_far_kernel(
         const Corner4<float> g = corner_setup<float>(xy.x, xy.y, H, W);
         const uint32_t rowf = (uint32_t)M * 32u;
         const uint32_t base = ((n * (uint32_t)S + (uint32_t)s_lsi[l]) * (uint32_t)M + m) * 32u + (uint32_t)ch;
-        const float tg = grad_out[pr * 32u + (uint32_t)ch], tgv = tg * a;
+        const float tg = ldval(grad_out, pr * 32u + (uint32_t)ch), tgv = tg * a;
         // an in-level corner takes part even when its weight is exactly 0 (its value still
         // enters d/d loc); out-of-level corners read as 0 and scatter nothing
-        const float v1 = g.ok1 ? value[base + (uint32_t)g.o1 * rowf] : 0.f;
-        const float v2 = g.ok2 ? value[base + (uint32_t)g.o2 * rowf] : 0.f;
-        const float v3 = g.ok3 ? value[base + (uint32_t)g.o3 * rowf] : 0.f;
-        const float v4 = g.ok4 ? value[base + (uint32_t)g.o4 * rowf] : 0.f;
+        const float v1 = g.ok1 ? ldval(value, base + (uint32_t)g.o1 * rowf) : 0.f;
+        const float v2 = g.ok2 ? ldval(value, base + (uint32_t)g.o2 * rowf) : 0.f;
+        const float v3 = g.ok3 ? ldval(value, base + (uint32_t)g.o3 * rowf) : 0.f;
+        const float v4 = g.ok4 ? ldval(value, base + (uint32_t)g.o4 * rowf) : 0.f;
         if (g.ok1) atomicAdd(grad_value + base + (uint32_t)g.o1 * rowf, g.k1 * tgv);
         if (g.ok2) atomicAdd(grad_value + base + (uint32_t)g.o2 * rowf, g.k2 * tgv);
         if (g.ok3) atomicAdd(grad_value + base + (uint32_t)g.o3 * rowf, g.k3 * tgv);
@@ -978,6 +1013,19 @@ int forward_impl<double>(const double *value, const int64_t *shapes, const int64
                                  static_cast<hipStream_t>(stream));
 }
 
+template <typename VT>
+void launch_forward_d32(const VT *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                        const float *aw, int S, int M, int L, int Lq, int P, size_t npairs, VT *out,
+                        hipStream_t st) {
+  const uint32_t nblk = (uint32_t)((npairs + 31) / 32);
+  if (P == 4 && aligned16(loc) && aligned16(aw))
+    hipLaunchKernelGGL((msda_fwd_d32_kernel<VT, true>), dim3(nblk), dim3(256), 0, st, value, shapes,
+                       lsi, loc, aw, S, M, L, Lq, P, (uint32_t)npairs, nblk, out);
+  else
+    hipLaunchKernelGGL((msda_fwd_d32_kernel<VT, false>), dim3(nblk), dim3(256), 0, st, value, shapes,
+                       lsi, loc, aw, S, M, L, Lq, P, (uint32_t)npairs, nblk, out);
+}
+
 template <>
 int forward_impl<float>(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *aw, int N, int S, int M, int D, int L,
@@ -990,13 +1038,7 @@ int forward_impl<float>(const float *value, const int64_t *shapes, const int64_t
   const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit &&
                      npairs * D < limit;
   if (D == 32 && small && aligned16(value) && aligned16(out)) {
-    const uint32_t nblk = (uint32_t)((npairs + 31) / 32);
-    if (P == 4 && aligned16(loc) && aligned16(aw))
-      hipLaunchKernelGGL(msda_fwd_f32_d32_kernel<true>, dim3(nblk), dim3(256), 0, st, value,
-                         shapes, lsi, loc, aw, S, M, L, Lq, P, (uint32_t)npairs, nblk, out);
-    else
-      hipLaunchKernelGGL(msda_fwd_f32_d32_kernel<false>, dim3(nblk), dim3(256), 0, st, value,
-                         shapes, lsi, loc, aw, S, M, L, Lq, P, (uint32_t)npairs, nblk, out);
+    launch_forward_d32<float>(value, shapes, lsi, loc, aw, S, M, L, Lq, P, npairs, out, st);
     return check_launch("msda_forward_f32");
   }
   return forward_generic<float>(value, shapes, lsi, loc, aw, N, S, M, D, L, Lq, P, out, st);
@@ -1056,6 +1098,21 @@ int backward_impl<double>(const char *who, const double *value, const int64_t *s
                                  static_cast<hipStream_t>(stream));
 }
 
+template <typename VT>
+int launch_backward_tiled(const char *who, const VT *value, const int64_t *shapes,
+                          const int64_t *lsi, const float *loc, const float *aw,
+                          const VT *grad_out, int N, int S, int M, int L, float *grad_value,
+                          float *grad_loc, float *grad_aw, hipStream_t st) {
+  const int cus = num_cus();
+  hipLaunchKernelGGL(tiled::msda_bwd_tiled_kernel<VT>, dim3(2 * cus), dim3(tiled::NT), 0, st,
+                     grad_out, value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc,
+                     grad_aw);
+  if (int rc = check_launch(who)) return rc;
+  hipLaunchKernelGGL(tiled::msda_bwd_far_kernel<VT>, dim3(8 * cus), dim3(256), 0, st, grad_out,
+                     value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc, grad_aw);
+  return check_launch(who);
+}
+
 template <>
 int backward_impl<float>(const char *who, const float *value, const int64_t *shapes,
                          const int64_t *lsi, const float *loc, const float *aw,
@@ -1072,14 +1129,8 @@ int backward_impl<float>(const char *who, const float *value, const int64_t *sha
   if (D == 32 && P == tiled::P && Lq == S && Lq > 0 && N > 0 && L <= tiled::MAXL && small &&
       aligned16(value) && aligned16(grad_out) && aligned16(grad_value) && aligned16(loc) &&
       aligned16(grad_loc) && tiled_allowed()) {
-    const int cus = num_cus();
-    hipLaunchKernelGGL(tiled::msda_bwd_tiled_kernel, dim3(2 * cus), dim3(tiled::NT), 0, st,
-                       grad_out, value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc,
-                       grad_aw);
-    if (int rc = check_launch(who)) return rc;
-    hipLaunchKernelGGL(tiled::msda_bwd_far_kernel, dim3(8 * cus), dim3(256), 0, st, grad_out,
-                       value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc, grad_aw);
-    return check_launch(who);
+    return launch_backward_tiled<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L,
+                                        grad_value, grad_loc, grad_aw, st);
   }
   return backward_atomic<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P,
                                 grad_value, grad_loc, grad_aw, st);
@@ -1135,6 +1186,52 @@ int msda_backward_f32(const float *value, const int64_t *spatial_shapes,
                               sampling_loc, attn_weight, grad_output, batch, spatial_size,
                               num_heads, channels, num_levels, num_query, num_point, grad_value,
                               grad_sampling_loc, grad_attn_weight, stream);
+}
+
+int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const float *sampling_loc,
+                      const float *attn_weight, int batch, int spatial_size, int num_heads,
+                      int channels, int num_levels, int num_query, int num_point, uint16_t *output,
+                      void *stream) {
+  const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels,
+            Lq = num_query, P = num_point;
+  if (int rc = check_dims("msda_forward_bf16", N, S, M, D, L, Lq, P)) return rc;
+  if ((size_t)N * Lq == 0) return MSDA_OK;
+  const size_t npairs = (size_t)N * Lq * M, limit = (size_t)1 << 30;
+  const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit && npairs * D < limit;
+  if (D != 32 || !small || (reinterpret_cast<uintptr_t>(value) & 7u) ||
+      (reinterpret_cast<uintptr_t>(output) & 7u))
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "msda_forward_bf16: needs channels == 32, 8-byte aligned tensors of < 2^30 elements");
+  launch_forward_d32<bf16_t>(reinterpret_cast<const bf16_t *>(value), spatial_shapes,
+                             level_start_index, sampling_loc, attn_weight, S, M, L, Lq, P, npairs,
+                             reinterpret_cast<bf16_t *>(output), static_cast<hipStream_t>(stream));
+  return check_launch("msda_forward_bf16");
+}
+
+int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                       const int64_t *level_start_index, const float *sampling_loc,
+                       const float *attn_weight, const uint16_t *grad_output, int batch,
+                       int spatial_size, int num_heads, int channels, int num_levels,
+                       int num_query, int num_point, float *grad_value, float *grad_sampling_loc,
+                       float *grad_attn_weight, void *stream) {
+  const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels,
+            Lq = num_query, P = num_point;
+  if (int rc = check_dims("msda_backward_bf16", N, S, M, D, L, Lq, P)) return rc;
+  const size_t npairs = (size_t)N * Lq * M, limit = (size_t)1 << 30;
+  const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit;
+  if (!(D == 32 && P == tiled::P && Lq == S && Lq > 0 && N > 0 && L <= tiled::MAXL && small) ||
+      (reinterpret_cast<uintptr_t>(value) & 7u) || (reinterpret_cast<uintptr_t>(grad_output) & 7u) ||
+      !aligned16(grad_value) || !aligned16(sampling_loc) || !aligned16(grad_sampling_loc))
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "msda_backward_bf16: needs the encoder shape (channels == 32, num_point == 4, "
+                "num_query == spatial_size, num_levels <= %d) and aligned tensors of < 2^30 elements",
+                tiled::MAXL);
+  return launch_backward_tiled<bf16_t>("msda_backward_bf16", reinterpret_cast<const bf16_t *>(value),
+                                       spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                       reinterpret_cast<const bf16_t *>(grad_output), N, S, M, L,
+                                       grad_value, grad_sampling_loc, grad_attn_weight,
+                                       static_cast<hipStream_t>(stream));
 }
 
 int msda_backward_f64(const double *value, const int64_t *spatial_shapes,

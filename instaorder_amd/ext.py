@@ -40,6 +40,8 @@ def _load():
         f.argtypes, f.restype = fwd_args, _I
         b = getattr(lib, "msda_backward_" + suffix)
         b.argtypes, b.restype = bwd_args, _I
+    lib.msda_forward_bf16.argtypes, lib.msda_forward_bf16.restype = fwd_args, _I
+    lib.msda_backward_bf16.argtypes, lib.msda_backward_bf16.restype = bwd_args, _I
     lib.msda_last_error.restype = ctypes.c_char_p
     lib.msda_launch_count.restype = ctypes.c_uint64
     lib.msda_abi_version.restype = _I
@@ -54,7 +56,7 @@ def launch_count():
     return int(_load().msda_launch_count())
 
 
-_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
 
 
 def _check_inputs(named):
@@ -71,9 +73,11 @@ def _common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
     if value.dtype not in _SUFFIX:
         # AT_DISPATCH_FLOATING_TYPES (ms_deform_attn_cuda.cu:69): float and double only
         raise RuntimeError('"ms_deform_attn" not implemented for \'%s\'' % value.dtype)
-    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
-        raise RuntimeError("expected sampling_loc and attn_weight to have value's dtype %s"
-                           % value.dtype)
+    # bf16 variant (an extension, not reference behaviour): bf16 value, fp32 locations/weights
+    side = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
+    if sampling_loc.dtype != side or attn_weight.dtype != side:
+        raise RuntimeError("expected sampling_loc and attn_weight of dtype %s for a %s value"
+                           % (side, value.dtype))
     if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
         raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
     if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
@@ -135,7 +139,10 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         raise RuntimeError("grad_output must be [N, Lq, M*D] with value's dtype")
     lib = _load()
     with torch.cuda.device(value.device):
-        grad_value = torch.empty_like(value)                    # zero-filled by the library
+        # fully written by the library; fp32 also for a bf16 value (the kernels accumulate and
+        # hand back grad_value in fp32 -- see include/msda_hip.h)
+        grad_value = torch.empty(value.shape, device=value.device,
+                                 dtype=torch.float32 if value.dtype == torch.bfloat16 else value.dtype)
         grad_sampling_loc = torch.empty_like(sampling_loc)
         grad_attn_weight = torch.empty_like(attn_weight)
         stream = torch.cuda.current_stream().cuda_stream

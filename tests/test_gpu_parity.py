@@ -264,3 +264,48 @@ def test_encoder_stack_gpu_runs_hip_path(msda):
     cpu.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
     ref, _, _ = cpu([x.cpu() for x in srcs], [pe(x.cpu()) for x in srcs])
     assert rel_err(memory.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+
+
+BF16_TOL = 1e-2       # north-star tolerance of the bf16 variant
+
+
+@pytest.mark.parametrize("dist,image,batch", [("model", 256, 3), ("uniform", 128, 2), ("model", 1024, 1)])
+def test_bf16_variant_vs_oracle(msda, oracle, dist, image, batch):
+    """bf16 value / output / grad_output, fp32 locations, weights, accumulation and gradients,
+    against the fp64 oracle run on the bf16-ROUNDED inputs."""
+    from instaorder_amd import ext, synthetic
+    inp = synthetic.make_inputs(batch, synthetic.encoder_shapes(image), dist=dist, seed=21)
+    v16 = inp["value"].to(torch.bfloat16)
+    go16 = inp["grad_output"].to(torch.bfloat16)
+    dev = {k: t.cuda() for k, t in inp.items()}
+    before = ext.launch_count()
+    out = msda.ms_deform_attn_forward(v16.cuda(), dev["spatial_shapes"], dev["level_start_index"],
+                                      dev["sampling_locations"], dev["attention_weights"], 128)
+    gv, gl, ga = msda.ms_deform_attn_backward(v16.cuda(), dev["spatial_shapes"],
+                                              dev["level_start_index"], dev["sampling_locations"],
+                                              dev["attention_weights"], go16.cuda(), 128)
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 3
+    assert out.dtype == torch.bfloat16 and gv.dtype == torch.float32
+    n = lambda t: t.double().numpy() if t.is_floating_point() else t.numpy()
+    args = (n(v16.float()), n(inp["spatial_shapes"]), n(inp["level_start_index"]),
+            n(inp["sampling_locations"]), n(inp["attention_weights"]))
+    o_out = oracle.forward(*args)
+    o_gv, o_gl, o_ga = oracle.backward(*args, n(go16.float()))
+    assert rel_err(out.float().cpu().numpy(), o_out) < BF16_TOL
+    # gradients are fp32 results of fp32 arithmetic on the rounded inputs: fp32-grade agreement
+    assert rel_err(gv.cpu().numpy(), o_gv) < GRAD_TOL_F32
+    assert rel_err(gl.cpu().numpy(), o_gl) < GRAD_TOL_F32
+    assert rel_err(ga.cpu().numpy(), o_ga) < GRAD_TOL_F32
+
+
+def test_bf16_variant_rejects_unsupported_shapes(msda):
+    shapes = torch.tensor([[4, 4]]).cuda()
+    lsi = torch.tensor([0]).cuda()
+    v = torch.randn(1, 16, 2, 16).to(torch.bfloat16).cuda()          # D = 16
+    with pytest.raises(RuntimeError, match="channels == 32"):
+        msda.ms_deform_attn_forward(v, shapes, lsi, torch.rand(1, 16, 2, 1, 4, 2).cuda(),
+                                    torch.rand(1, 16, 2, 1, 4).cuda(), 128)
+    with pytest.raises(RuntimeError, match="dtype"):
+        msda.ms_deform_attn_forward(v, shapes, lsi, torch.rand(1, 16, 2, 1, 4, 2).cuda().bfloat16(),
+                                    torch.rand(1, 16, 2, 1, 4).cuda(), 128)
