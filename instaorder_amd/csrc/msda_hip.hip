@@ -113,6 +113,8 @@ __device__ __forceinline__ Corner4<T> corner_setup(T lx, T ly, int H, int W) {
 // lane carries its 4 channels through all L*P samples.  Sampling locations and weights of
 // a (pair, level) are fetched as three 16-B loads (P == 4) that the 8 lanes of a pair
 // share through the L1 broadcast.
+// The kernel asks for 4 waves/SIMD (not 8) so the compiler keeps all 16 corner loads of a level
+// in flight at once (+6 % measured).
 // All offsets are 32-bit byte offsets from the (wave-uniform) tensor base, which lets the
 // loads use the SGPR-base + VGPR-offset form (the host checks every tensor is < 4 GiB).
 // =======================================================================================
@@ -186,7 +188,7 @@ __device__ __forceinline__ void fwd_samples_d32(const VT *__restrict__ value, ui
 }
 
 template <typename VT, bool P4>
-__global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_fwd_d32_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ aw, int S, int M, int L, int Lq, int P, uint32_t npairs,
