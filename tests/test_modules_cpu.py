@@ -88,3 +88,26 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert r1["n_gpus"] == 1 and r2["n_gpus"] == 2
     assert r2["unit"] == "imgs/s" and r2["value"] > 0
+
+
+def test_config_c1_cpu_forward_512():
+    """BASELINE.json configs[0]: CPU forward at the 512^2 shape (levels 16^2/32^2/64^2, S=5376)
+    goes through the PyTorch path of the module -- the reference's CPU behaviour -- and agrees
+    with the C oracle on the op's inputs."""
+    from instaorder_amd import MSDeformAttn, synthetic, ms_deform_attn_core_pytorch
+    from oracle import msda_oracle
+    torch.manual_seed(0)
+    shapes = synthetic.encoder_shapes(512)
+    inp = synthetic.make_inputs(1, shapes, dist="model", seed=3)
+    out = ms_deform_attn_core_pytorch(inp["value"], inp["spatial_shapes"], inp["sampling_locations"],
+                                      inp["attention_weights"])
+    ref = msda_oracle.forward(inp["value"].numpy(), inp["spatial_shapes"].numpy(),
+                              inp["level_start_index"].numpy(), inp["sampling_locations"].numpy(),
+                              inp["attention_weights"].numpy())
+    assert rel_err(out.numpy(), ref) < 1e-5
+    mod = MSDeformAttn(256, 3, 8, 4)
+    s = sum(h * w for h, w in shapes)
+    x = torch.randn(1, s, 256)
+    ref_pts = synthetic.reference_points(shapes)[None, :, None, :].expand(1, s, 3, 2)
+    y = mod(x, ref_pts, x, inp["spatial_shapes"], inp["level_start_index"])
+    assert tuple(y.shape) == (1, s, 256) and torch.isfinite(y).all()
