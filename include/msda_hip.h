@@ -14,14 +14,18 @@
  *     attn_weight [N,Lq,M,L,P], output / grad_output [N,Lq,M*D];
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); work is
  *     enqueued asynchronously, nothing synchronises with the host;
- *   - no allocation, no exceptions; return 0 on success, non-zero on error, and
- *     msda_last_error() then returns a thread-local message;
- *   - every output element is written (no pre-zeroing needed by the caller):
- *     msda_backward_* zero-fills grad_value on `stream` before accumulating into it.
+ *   - no exceptions; return 0 on success, non-zero on error, and msda_last_error() then
+ *     returns a thread-local message;
+ *   - no allocation, with one exception: msda_backward_f32 / msda_backward_bf16 on the
+ *     channels == 32 fast path take their workspace from the device's stream-ordered pool
+ *     (hipMallocAsync / hipFreeAsync on `stream`, no host synchronisation); callers that must
+ *     not allocate pass their own workspace to the *_ws variants;
+ *   - every output element is written (no pre-zeroing needed by the caller).
  */
 #ifndef MSDA_HIP_H_
 #define MSDA_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -66,15 +70,33 @@ int msda_forward_f64(const double *value, const int64_t *spatial_shapes,
  * Backward.  Replaces ms_deformable_col2im_cuda<float|double>
  * (src/cuda/ms_deform_im2col_cuda.cuh:961-1332, every kernel variant it dispatches to)
  * as called from ms_deform_attn_cuda_backward (src/cuda/ms_deform_attn_cuda.cu:136-153).
- * grad_value is zero-filled inside (the reference's caller does at::zeros_like,
+ * grad_value needs no zero-fill by the caller (the reference's caller does at::zeros_like,
  * ms_deform_attn_cuda.cu:126); grad_sampling_loc and grad_attn_weight are fully written.
+ *
+ * channels == 32, num_point <= 8, num_levels <= 8 (every InstaFormer configuration) runs the
+ * binned destination-tiled kernels, which sort the samples by destination tile in a workspace
+ * of msda_backward_workspace_bytes(...) bytes; other shapes run the generic atomic kernels and
+ * need none.  The *_ws variants take the workspace from the caller (any device memory, 4-byte
+ * aligned, contents irrelevant before and after; calls sharing one workspace must be ordered
+ * on one stream); the plain variants take it from the stream-ordered pool.
  */
+size_t msda_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                     int num_levels, int num_query, int num_point);
+
 int msda_backward_f32(const float *value, const int64_t *spatial_shapes,
                       const int64_t *level_start_index, const float *sampling_loc,
                       const float *attn_weight, const float *grad_output, int batch,
                       int spatial_size, int num_heads, int channels, int num_levels,
                       int num_query, int num_point, float *grad_value,
                       float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
+int msda_backward_f32_ws(const float *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start_index, const float *sampling_loc,
+                         const float *attn_weight, const float *grad_output, int batch,
+                         int spatial_size, int num_heads, int channels, int num_levels,
+                         int num_query, int num_point, float *grad_value,
+                         float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
                       const int64_t *level_start_index, const double *sampling_loc,
@@ -89,8 +111,8 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
  * pixel_decoder/msdeformattn.py:435-441).  value / output / grad_output are bfloat16 bit
  * patterns (uint16_t); sampling locations, attention weights and ALL THREE gradients are fp32;
  * accumulation is fp32.  grad_value comes back in fp32 (algorithmic bytes 68.00 B/sample, not
- * 62.67).  Forward needs channels == 32; backward needs the encoder shape (channels == 32,
- * num_point == 4, num_query == spatial_size).  Same kernels as the fp32 fast paths.
+ * 62.67).  Both need channels == 32 (backward also num_point <= 8, num_levels <= 8).  Same
+ * kernels as the fp32 fast paths; msda_backward_bf16_ws as msda_backward_f32_ws.
  */
 int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                       const int64_t *level_start_index, const float *sampling_loc,
@@ -104,6 +126,14 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                        int spatial_size, int num_heads, int channels, int num_levels,
                        int num_query, int num_point, float *grad_value,
                        float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
+int msda_backward_bf16_ws(const uint16_t *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start_index, const float *sampling_loc,
+                          const float *attn_weight, const uint16_t *grad_output, int batch,
+                          int spatial_size, int num_heads, int channels, int num_levels,
+                          int num_query, int num_point, float *grad_value,
+                          float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -917,6 +917,575 @@ __global__ __launch_bounds__(256) void msda_bwd_far_kernel(
 
 }  // namespace tiled
 
+// =======================================================================================
+// Backward, fp32 arithmetic, D == 32, P <= 4, any Lq: *binned* destination-tiled backward.
+//
+// Same accumulation scheme as msda_bwd_tiled_kernel above (a workgroup owns the 256
+// grad_value rows of one (image, head, level, 16x16 tile) in registers; per-pixel LDS buckets
+// filled with integer LDS atomics; no float atomic anywhere), but the workgroup no longer
+// *searches* a candidate rectangle for the samples that land in its tile: a counting sort
+// hands every tile the list of its samples.  That removes most of the examination redundancy
+// (3.5 candidates per hit -> 1.3), the near/far split (any distribution of sampling locations
+// runs through the same kernels, no atomics) and the Lq == S restriction.
+//
+//   A list entry is one *quad* -- the (up to 4) points of one (image, query, head, level) --
+//   plus a mask of the points that have at least one in-level corner inside the tile; a quad
+//   is listed once in every tile its points touch (model-like locations: 1.35 tiles per quad,
+//   3.0 of 4 points live per entry).  Four threads examine one entry, one point each, exactly
+//   as the candidate kernel examined one query; everything after the examination is shared.
+//
+// Kernels, all on the caller's stream, all reading the level shapes on the device:
+//   msda_bwd_bin_zero_kernel    clears the per-tile counters,
+//   msda_bwd_bin_kernel<false>  counts entries per (image, level, tile, head) -- LDS histogram
+//                               per workgroup, one global atomic per touched key,
+//   msda_bwd_bin_scan_kernel    exclusive prefix sum -> list starts,
+//   msda_bwd_bin_kernel<true>   writes the entries to their lists, and the zero gradients of
+//                               gate-closed samples,
+//   msda_bwd_binned_kernel      the tile kernel.
+// Workspace (caller-provided), uint32 words: counters[key_cap + 1], starts[key_cap + 1],
+// entries[16 * quads]; key_cap = N*M*S >= number of lists (a level has at most H*W tiles), and
+// a quad touches at most 16 tiles (typically 1-2: the bound is address space, not traffic).
+// =======================================================================================
+namespace binned {
+
+#ifdef MSDA_PHASE_STAMPS
+using tiled::g_phase_cycles;
+#endif
+using tiled::sum2;
+using tiled::uni;
+using tiled::unif;
+
+constexpr int T = 16;
+constexpr int TP = T * T;
+constexpr int VT = T + 1;
+constexpr int ZROW = VT * VT;
+constexpr int NT = 512;
+constexpr int CE = NT / 4;        // list entries per chunk: four threads (one per point) per entry
+constexpr int MAXL = 8;
+constexpr int MAXP = 4;           // entry = (n*Lq + q) << 4 | point mask
+constexpr int KB = 8;
+constexpr int KCAP = 8192;        // lists per image the binning kernels can histogram in LDS
+constexpr int BIN_NT = 256;
+constexpr int BIN_QPT = 8;        // quads per thread of the binning kernels
+constexpr int BIN_QB = BIN_NT * BIN_QPT;
+constexpr int MAX_ENTRIES_PER_QUAD = 16;
+
+struct Levels {
+  int H[MAXL], W[MAXL], lsi[MAXL], ntx[MAXL], toff[MAXL + 1];
+};
+
+// thread 0 of a workgroup fills the table; caller synchronises
+__device__ __forceinline__ void load_levels(Levels &lv, const int64_t *__restrict__ shapes,
+                                            const int64_t *__restrict__ lsi, int L) {
+  int to = 0;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    lv.H[l] = H;
+    lv.W[l] = W;
+    lv.lsi[l] = lsi ? (int)lsi[l] : 0;
+    lv.ntx[l] = (W + T - 1) / T;
+    lv.toff[l] = to;
+    to += ((H + T - 1) / T) * ((W + T - 1) / T);
+  }
+  lv.toff[L] = to;
+}
+
+__device__ __forceinline__ uint64_t count_lists(const int64_t *__restrict__ shapes, int N, int M, int L) {
+  int to = 0;
+  for (int l = 0; l < L; ++l)
+    to += (((int)shapes[2 * l] + T - 1) / T) * (((int)shapes[2 * l + 1] + T - 1) / T);
+  return (uint64_t)N * (uint64_t)to * (uint64_t)M;
+}
+
+__global__ __launch_bounds__(256) void msda_bwd_bin_zero_kernel(const int64_t *__restrict__ shapes,
+                                                                int N, int M, int L, uint32_t key_cap,
+                                                                uint32_t *__restrict__ counts) {
+  const uint64_t nkeys = count_lists(shapes, N, M, L);
+  if (nkeys > key_cap) return;
+  for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k <= nkeys; k += (uint64_t)gridDim.x * 256u)
+    counts[k] = 0u;
+}
+
+// Tile rows / columns spanned by the in-level corners of one sample (a == b when both rows,
+// or both columns, fall in the same tile or only one is inside the level).  corner_setup's
+// own floor is used, so the tile kernel -- which recomputes the geometry from the same
+// location -- finds the sample in exactly these tiles.
+struct PointTiles {
+  int tya, tyb, txa, txb;
+  bool in;
+};
+__device__ __forceinline__ PointTiles point_tiles(float lx, float ly, int H, int W) {
+  const Corner4<float> g = corner_setup<float>(lx, ly, H, W);
+  PointTiles t;
+  t.in = g.in;
+  const int ra = g.h0 >= 0 ? g.h0 : g.h0 + 1, rb = g.h0 + 1 <= H - 1 ? g.h0 + 1 : g.h0;
+  const int ca = g.w0 >= 0 ? g.w0 : g.w0 + 1, cb = g.w0 + 1 <= W - 1 ? g.w0 + 1 : g.w0;
+  t.tya = ra / T;
+  t.tyb = rb / T;
+  t.txa = ca / T;
+  t.txb = cb / T;
+  return t;
+}
+
+// Calls f(tile_y, tile_x, mask) once per list the quad belongs to.  When the quad's points
+// span at most 2 x 2 tiles (the rule for model-like locations) every tile is listed once with
+// the mask of all points touching it; otherwise each point is listed on its own.
+template <typename F>
+__device__ __forceinline__ void for_each_entry(const PointTiles (&pt)[4], F &&f) {
+  int tymin = 1 << 30, tymax = -1, txmin = 1 << 30, txmax = -1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (pt[j].in) {
+      tymin = min(tymin, pt[j].tya);
+      tymax = max(tymax, pt[j].tyb);
+      txmin = min(txmin, pt[j].txa);
+      txmax = max(txmax, pt[j].txb);
+    }
+  if (tymax < 0) return;
+  if (tymax - tymin <= 1 && txmax - txmin <= 1) {
+    for (int ty = tymin; ty <= tymax; ++ty)
+      for (int tx = txmin; tx <= txmax; ++tx) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (pt[j].in && (ty == pt[j].tya || ty == pt[j].tyb) && (tx == pt[j].txa || tx == pt[j].txb))
+            mask |= 1u << j;
+        if (mask) f(ty, tx, mask);
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (pt[j].in)
+        for (int ty = pt[j].tya; ty <= pt[j].tyb; ++ty)
+          for (int tx = pt[j].txa; tx <= pt[j].txb; ++tx) f(ty, tx, 1u << j);
+  }
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(BIN_NT) void msda_bwd_bin_kernel(
+    const int64_t *__restrict__ shapes, const float *__restrict__ loc, int N, int M, int L, int Lq,
+    int P, uint32_t qpi, uint32_t bpi, uint32_t key_cap, uint32_t *__restrict__ counts,
+    uint32_t *__restrict__ entries, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
+  __shared__ uint32_t s_hist[KCAP];
+  __shared__ Levels lv;
+  const int tid = threadIdx.x;
+  if (tid == 0) load_levels(lv, shapes, nullptr, L);
+  __syncthreads();
+  const uint32_t keys_img = (uint32_t)lv.toff[L] * (uint32_t)M;
+  if ((uint64_t)N * keys_img > key_cap) return;        // shapes break the sum(H*W) == S contract
+  const bool use_lds = keys_img <= (uint32_t)KCAP;
+  const uint32_t n = blockIdx.x / bpi, base = (blockIdx.x % bpi) * (uint32_t)BIN_QB;
+  const uint32_t gk0 = n * keys_img;
+  const uint32_t ML = (uint32_t)(M * L);
+  const uint32_t q0 = n * qpi;                          // first quad of this image
+
+  // quad i of the image -> its points' tiles; returns the quad's (query, head, level)
+  auto examine = [&](uint32_t i, PointTiles (&pt)[4], uint32_t &q, uint32_t &m, uint32_t &l) {
+    q = i / ML;
+    const uint32_t r = i - q * ML;
+    m = r / (uint32_t)L;
+    l = r - m * (uint32_t)L;
+    const int H = lv.H[l], W = lv.W[l];
+    const float *lp = loc + 2u * (q0 + i) * (uint32_t)P;
+    if (P == 4) {
+      const float4 a = *reinterpret_cast<const float4 *>(lp), b = *reinterpret_cast<const float4 *>(lp + 4);
+      pt[0] = point_tiles(a.x, a.y, H, W);
+      pt[1] = point_tiles(a.z, a.w, H, W);
+      pt[2] = point_tiles(b.x, b.y, H, W);
+      pt[3] = point_tiles(b.z, b.w, H, W);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < P) {
+          pt[j] = point_tiles(lp[2 * j], lp[2 * j + 1], H, W);
+        } else {
+          pt[j].in = false;
+          pt[j].tya = pt[j].tyb = pt[j].txa = pt[j].txb = 0;
+        }
+      }
+    }
+  };
+
+  if (use_lds) {
+    for (uint32_t k = tid; k < keys_img; k += BIN_NT) s_hist[k] = 0u;
+    __syncthreads();
+  }
+  if (use_lds || !SCATTER) {
+    for (int r = 0; r < BIN_QPT; ++r) {
+      const uint32_t i = base + (uint32_t)(r * BIN_NT + tid);
+      if (i >= qpi) continue;
+      PointTiles pt[4];
+      uint32_t q, m, l;
+      examine(i, pt, q, m, l);
+      const int toff = lv.toff[l], ntx = lv.ntx[l];
+      for_each_entry(pt, [&](int ty, int tx, uint32_t) {
+        const uint32_t key = (uint32_t)(toff + ty * ntx + tx) * (uint32_t)M + m;
+        if (use_lds)
+          atomicAdd(&s_hist[key], 1u);
+        else
+          atomicAdd(&counts[gk0 + key], 1u);
+      });
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t k = tid; k < keys_img; k += BIN_NT) {
+      const uint32_t c = s_hist[k];
+      if (c) {
+        const uint32_t old = atomicAdd(&counts[gk0 + k], c);   // SCATTER: counts holds the cursors
+        if (SCATTER) s_hist[k] = old;
+      }
+    }
+  }
+  if (!SCATTER) return;
+  __syncthreads();
+  for (int r = 0; r < BIN_QPT; ++r) {
+    const uint32_t i = base + (uint32_t)(r * BIN_NT + tid);
+    if (i >= qpi) continue;
+    PointTiles pt[4];
+    uint32_t q, m, l;
+    examine(i, pt, q, m, l);
+    const int toff = lv.toff[l], ntx = lv.ntx[l];
+    const uint32_t ent = (n * (uint32_t)Lq + q) << 4;
+    for_each_entry(pt, [&](int ty, int tx, uint32_t mask) {
+      const uint32_t key = (uint32_t)(toff + ty * ntx + tx) * (uint32_t)M + m;
+      const uint32_t pos = use_lds ? atomicAdd(&s_hist[key], 1u) : atomicAdd(&counts[gk0 + key], 1u);
+      entries[pos] = ent | mask;
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < P && !pt[j].in) {                          // gate closed: zero gradients
+        const uint32_t s = (q0 + i) * (uint32_t)P + (uint32_t)j;
+        grad_aw[s] = 0.f;
+        *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2(0.f, 0.f);
+      }
+  }
+}
+
+// One workgroup: offs[k] = sum of counts[0..k), counts[k] = the same (the scatter's cursors).
+__global__ __launch_bounds__(1024) void msda_bwd_bin_scan_kernel(const int64_t *__restrict__ shapes,
+                                                                 int N, int M, int L, uint32_t key_cap,
+                                                                 uint32_t *__restrict__ counts,
+                                                                 uint32_t *__restrict__ offs) {
+  __shared__ uint32_t s_wave[16];
+  const uint64_t nk64 = count_lists(shapes, N, M, L);
+  if (nk64 > key_cap) return;
+  const uint32_t nkeys = (uint32_t)nk64;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // tiles of 1024 consecutive keys (coalesced), carried sequentially
+  uint32_t carry = 0;
+  for (uint32_t k0 = 0; k0 < nkeys; k0 += 1024u) {
+    const uint32_t k = k0 + tid;
+    const uint32_t c = k < nkeys ? counts[k] : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if ((int)lane >= d) inc += o;
+    }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (uint32_t w = 0; w < 16u; ++w) {
+      const uint32_t v = s_wave[w];
+      if (w < wave) wbase += v;
+      tot += v;
+    }
+    const uint32_t ex = carry + wbase + inc - c;
+    if (k < nkeys) {
+      offs[k] = ex;
+      counts[k] = ex;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) offs[nkeys] = carry;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
+    const ST *__restrict__ grad_out, const ST *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ loc, const float *__restrict__ aw,
+    const uint32_t *__restrict__ offs, const uint32_t *__restrict__ entries, uint32_t key_cap,
+    int N, int S, int M, int L, int P, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
+  __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
+  __shared__ float4 s_go[CE * 8];           // grad_output rows of this chunk's entries
+  __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (entry slot, weight bits)
+  __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
+  __shared__ uint32_t s_q[CE];              // n*Lq + q of each slot of the chunk
+  __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
+  __shared__ uint32_t s_max[2];
+  __shared__ uint32_t s_hcount[2];
+  __shared__ uint32_t s_list[2];
+  __shared__ Levels lv;
+
+  const int tid = threadIdx.x;
+  if (tid == 0) load_levels(lv, shapes, lsi, L);
+  __syncthreads();
+  const uint32_t I_img = (uint32_t)uni(lv.toff[L]) * (uint32_t)M;
+  if ((uint64_t)N * I_img > key_cap) return;
+  const uint32_t total_items = (uint32_t)N * I_img;
+  MSDA_STAMP_DECL
+
+  const uint32_t slot = (uint32_t)tid >> 2, p = (uint32_t)tid & 3u;      // exam: entry slot, point
+  const uint32_t gslot = (uint32_t)tid >> 3, gsub = (uint32_t)tid & 7u;   // rows gslot, gslot + 64
+
+  for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+    const uint32_t n = item / I_img, ri = item - n * I_img;
+    const uint32_t tl = ri / (uint32_t)M, m = ri - tl * (uint32_t)M;
+    int l = 0;
+    while (l + 1 < L && (int)tl >= uni(lv.toff[l + 1])) ++l;
+    const int H = uni(lv.H[l]), W = uni(lv.W[l]), ntx = uni(lv.ntx[l]);
+    const int tile = (int)tl - uni(lv.toff[l]);
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    const int y0 = ty * T, x0 = tx * T;
+    const int th = min(T, H - y0), tw = min(T, W - x0);
+
+    if (tid == 0) {
+      s_list[0] = offs[item];
+      s_list[1] = offs[item + 1u];
+      s_hcount[0] = 0;
+      s_hcount[1] = 0;
+      s_max[0] = 0;
+      s_max[1] = 0;
+    }
+    // value tile -> LDS (zeros outside the level), counters cleared
+    {
+      const uint32_t lrow = n * (uint32_t)S + (uint32_t)uni(lv.lsi[l]);
+      for (int t = tid; t < (ZROW + 1) * 8; t += NT) {
+        const int row = t >> 3, sub = t & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < ZROW) {
+          const int y = y0 + row / VT, x = x0 + row % VT;
+          if (y < H && x < W)
+            v = ldrow4(value, ((lrow + (uint32_t)(y * W + x)) * (uint32_t)M + m) * 128u +
+                                (uint32_t)sub * 16u);
+        }
+        s_vt[row * 8 + sub] = v;
+      }
+      for (int t = tid; t < 2 * (TP + 64); t += NT) (&s_cnt[0][0])[t] = 0;
+    }
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const uint32_t list0 = (uint32_t)uni((int)s_list[0]);
+    const uint32_t total = (uint32_t)uni((int)s_list[1]) - list0;
+    const uint32_t nchunks = (total + (uint32_t)CE - 1u) / (uint32_t)CE;
+    auto eidx = [&](uint32_t c, uint32_t j) -> uint32_t { return c * (uint32_t)CE + j; };
+    // entries of chunk `c` this thread needs: its exam slot and the two rows it stages
+    auto load_ids = [&](uint32_t c, uint32_t &ent, uint32_t &r0, uint32_t &r1) {
+      const uint32_t e = eidx(c, slot), e0 = eidx(c, gslot), e1 = eidx(c, gslot + 64u);
+      ent = e < total ? entries[list0 + e] : 0u;          // mask 0: nothing to examine
+      if (e0 < total) r0 = entries[list0 + e0];
+      if (e1 < total) r1 = entries[list0 + e1];
+    };
+    auto sample_of = [&](uint32_t ent) -> uint32_t {
+      return (((ent >> 4) * (uint32_t)M + m) * (uint32_t)L + (uint32_t)l) * (uint32_t)P + p;
+    };
+    auto load_sample = [&](uint32_t ent, float2 &xy, float &a) {
+      if ((ent >> p) & 1u) {
+        const uint32_t s = sample_of(ent);
+        xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
+        a = aw[s];
+      }
+    };
+    auto load_rows = [&](uint32_t c, uint32_t r0, uint32_t r1, float4 &g0, float4 &g1) {
+      if (eidx(c, gslot) < total) g0 = ldrow4(grad_out, ((r0 >> 4) * (uint32_t)M + m) * 128u + gsub * 16u);
+      if (eidx(c, gslot + 64u) < total) g1 = ldrow4(grad_out, ((r1 >> 4) * (uint32_t)M + m) * 128u + gsub * 16u);
+    };
+
+    // Software pipeline: ids two chunks ahead, (location, weight) and grad_output rows one ahead.
+    uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0, nn_ent = 0, nn_r0 = 0, nn_r1 = 0;
+    float2 c_xy = make_float2(0.f, 0.f);
+    float c_a = 0.f;
+    float4 c_g0 = make_float4(0.f, 0.f, 0.f, 0.f), c_g1 = c_g0;
+    if (nchunks > 0) {
+      uint32_t r0 = 0, r1 = 0;
+      load_ids(0, c_ent, r0, r1);
+      if (nchunks > 1) load_ids(1, n_ent, n_r0, n_r1);
+      load_sample(c_ent, c_xy, c_a);
+      load_rows(0, r0, r1, c_g0, c_g1);
+    }
+    MSDA_STAMP(0)   // item setup
+
+    for (uint32_t chunk = 0; chunk < nchunks; ++chunk) {
+      // ---------------- phase A: examine one point of one list entry per thread ----------------
+      const int par = (int)(chunk & 1u);
+      bool own1 = false, own2 = false, own3 = false, own4 = false, home = false;
+      int r1 = 0;
+      float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+      float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef MSDA_PHASE_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MSDA_STAMP(8)
+#endif
+      if ((c_ent >> p) & 1u) {
+        const float a = c_a;
+        const Corner4<float> g = corner_setup<float>(c_xy.x, c_xy.y, H, W);
+        const int ly0 = g.h0 - y0, lx0 = g.w0 - x0;       // corner 1 in tile coordinates
+        const bool yin0 = (unsigned)ly0 < (unsigned)th, yin1 = (unsigned)(ly0 + 1) < (unsigned)th;
+        const bool xin0 = (unsigned)lx0 < (unsigned)tw, xin1 = (unsigned)(lx0 + 1) < (unsigned)tw;
+        own1 = g.ok1 && yin0 && xin0;
+        own2 = g.ok2 && yin0 && xin1;
+        own3 = g.ok3 && yin1 && xin0;
+        own4 = g.ok4 && yin1 && xin1;
+        r1 = ly0 * T + lx0;
+        w1 = g.k1 * a;
+        w2 = g.k2 * a;
+        w3 = g.k3 * a;
+        w4 = g.k4 * a;
+        const int hy = max(g.h0, 0) - y0, hx = max(g.w0, 0) - x0;
+        home = g.in && (unsigned)hy < (unsigned)th && (unsigned)hx < (unsigned)tw;
+        if (home) {
+          const uint32_t ok = (g.ok1 ? 1u : 0u) | (g.ok2 ? 2u : 0u) | (g.ok3 ? 4u : 0u) |
+                              (g.ok4 ? 8u : 0u);
+          const uint32_t pk = (uint32_t)(ly0 + 1) | ((uint32_t)(lx0 + 1) << 5) | (ok << 10) |
+                              ((uint32_t)tid << 14);
+          hrec = make_float4(g.lh, g.lw, a, __uint_as_float(pk));
+        }
+      }
+      MSDA_STAMP(9)
+      const int dummy = TP + (tid & 63);
+      const uint32_t pos1 = atomicAdd(&s_cnt[par][own1 ? r1 : dummy], 1u);
+      const uint32_t pos2 = atomicAdd(&s_cnt[par][own2 ? r1 + 1 : dummy], 1u);
+      const uint32_t pos3 = atomicAdd(&s_cnt[par][own3 ? r1 + T : dummy], 1u);
+      const uint32_t pos4 = atomicAdd(&s_cnt[par][own4 ? r1 + T + 1 : dummy], 1u);
+      MSDA_STAMP(10)
+      if (chunk + 1u < nchunks) load_sample(n_ent, c_xy, c_a);               // consumed next chunk
+      if (chunk + 2u < nchunks) load_ids(chunk + 2u, nn_ent, nn_r0, nn_r1);
+      {
+        const uint32_t top = max(max(own1 ? pos1 : 0u, own2 ? pos2 : 0u),
+                                 max(own3 ? pos3 : 0u, own4 ? pos4 : 0u));
+        if (top >= (uint32_t)KB) atomicMax(&s_max[par], top);   // a bucket overflowed
+      }
+      MSDA_STAMP(1)
+      __syncthreads();   // every wave is past phases D/E of the previous chunk
+      MSDA_STAMP(2)
+      // ---------------- phase C: contributions -> pixel buckets; rows, home list -> LDS ----------------
+      s_go[gslot * 8u + gsub] = c_g0;
+      s_go[(gslot + 64u) * 8u + gsub] = c_g1;
+      if (chunk + 1u < nchunks) load_rows(chunk + 1u, n_r0, n_r1, c_g0, c_g1);
+      if (p == 0u) s_q[slot] = c_ent >> 4;
+      if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
+      for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
+      if (tid == 0) {
+        s_hcount[par ^ 1] = 0u;
+        s_max[par ^ 1] = 0u;
+      }
+      const uint32_t rounds = (uint32_t)uni((int)s_max[par]) / (uint32_t)KB + 1u;   // 1 unless a bucket overflowed
+      MSDA_STAMP(3)
+      for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t lo = r * (uint32_t)KB;
+        if (r > 0) __syncthreads();                                     // previous round consumed
+        if (own1 && pos1 - lo < (uint32_t)KB)
+          s_rec[r1 * KB + (int)(pos1 - lo)] = make_uint2(slot, __float_as_uint(w1));
+        if (own2 && pos2 - lo < (uint32_t)KB)
+          s_rec[(r1 + 1) * KB + (int)(pos2 - lo)] = make_uint2(slot, __float_as_uint(w2));
+        if (own3 && pos3 - lo < (uint32_t)KB)
+          s_rec[(r1 + T) * KB + (int)(pos3 - lo)] = make_uint2(slot, __float_as_uint(w3));
+        if (own4 && pos4 - lo < (uint32_t)KB)
+          s_rec[(r1 + T + 1) * KB + (int)(pos4 - lo)] = make_uint2(slot, __float_as_uint(w4));
+        if (r == 0) {
+          MSDA_STAMP(4)
+        }
+        __syncthreads();
+        if (r == 0) {
+          MSDA_STAMP(7)
+        }
+        // ---------------- phase D: every pixel's owners sum their bucket ----------------
+        const int px = tid >> 1, half = tid & 1;
+        const uint32_t cnt = s_cnt[par][px];
+        const int nrec = (int)min(cnt > lo ? cnt - lo : 0u, (uint32_t)KB);
+        for (int i = 0; i < nrec; i += 2) {
+          const uint4 rr = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i]);
+          const bool two = i + 1 < nrec;
+          const int rowa = (int)rr.x, rowb = two ? (int)rr.z : 0;
+          const float wa = __uint_as_float(rr.y), wb = two ? __uint_as_float(rr.w) : 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = half * 4 + ((k + px) & 3);     // this lane's k-th chunk (see flush)
+            const float4 ga = s_go[rowa * 8 + c];
+            const float4 gb = s_go[rowb * 8 + c];
+            acc[k].x += wa * ga.x + wb * gb.x;
+            acc[k].y += wa * ga.y + wb * gb.y;
+            acc[k].z += wa * ga.z + wb * gb.z;
+            acc[k].w += wa * ga.w + wb * gb.w;
+          }
+        }
+      }
+      MSDA_STAMP(5)
+      // ---------------- phase E: gradients of the samples this tile is home to ----------------
+      {
+        const uint32_t hc = (uint32_t)uni((int)s_hcount[par]);
+        const int half = tid & 1;
+        for (uint32_t h = (uint32_t)tid >> 1; h < hc; h += NT / 2) {
+          const float4 hr = s_home[h];
+          const uint32_t pk = __float_as_uint(hr.w);
+          const int by = (int)(pk & 31u) - 1, bx = (int)((pk >> 5) & 31u) - 1;
+          const uint32_t ok = (pk >> 10) & 15u, et = pk >> 14;      // et: examining thread
+          const int hslot = (int)(et >> 2);
+          const int rb = by * VT + bx;
+          const int ra = (ok & 1u) ? rb : ZROW, rbb = (ok & 2u) ? rb + 1 : ZROW;
+          const int rc = (ok & 4u) ? rb + VT : ZROW, rd = (ok & 8u) ? rb + VT + 1 : ZROW;
+          float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = half * 4 + ((k + (int)h) & 3);
+            const float4 g4 = s_go[hslot * 8 + c];
+            const float4 v1 = s_vt[ra * 8 + c];
+            const float4 v2 = s_vt[rbb * 8 + c];
+            const float4 v3 = s_vt[rc * 8 + c];
+            const float4 v4 = s_vt[rd * 8 + c];
+            d1 += g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w;
+            d2 += g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w;
+            d3 += g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w;
+            d4 += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+          }
+          d1 = sum2(d1);
+          d2 = sum2(d2);
+          d3 = sum2(d3);
+          d4 = sum2(d4);
+          if (half == 0) {
+            const float lh = hr.x, lw = hr.y, a = hr.z, hh = 1.f - lh, hw = 1.f - lw;
+            const uint32_t s = ((s_q[hslot] * (uint32_t)M + m) * (uint32_t)L + (uint32_t)l) * (uint32_t)P + (et & 3u);
+            grad_aw[s] = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
+            const float gw = (float)W * a * (hh * (d2 - d1) + lh * (d4 - d3));
+            const float gh = (float)H * a * (hw * (d3 - d1) + lw * (d4 - d2));
+            *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2(gw, gh);
+          }
+        }
+      }
+      MSDA_STAMP(6)
+      c_ent = n_ent;
+      n_ent = nn_ent;
+      n_r0 = nn_r0;
+      n_r1 = nn_r1;
+    }
+    // ---------------- flush the tile's grad_value rows (sole owner: plain stores) ----------------
+    {
+      const int px = tid >> 1, half = tid & 1;
+      const int py = px / T, pxx = px % T;
+      if (py < th && pxx < tw) {
+        const uint32_t rowi = n * (uint32_t)S + (uint32_t)uni(lv.lsi[l]) + (uint32_t)((y0 + py) * W + x0 + pxx);
+        float4 *dst = reinterpret_cast<float4 *>(
+            reinterpret_cast<char *>(grad_value) +
+            ((size_t)(rowi * (uint32_t)M + m) * 128u + (size_t)half * 64u));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[(k + px) & 3] = acc[k];
+      }
+    }
+    __syncthreads();
+    MSDA_STAMP(0)
+  }
+  MSDA_STAMP_FLUSH
+}
+
+}  // namespace binned
+
 // ---------------------------------------------------------------------------------------
 // Host side.
 // ---------------------------------------------------------------------------------------
@@ -1060,12 +1629,6 @@ int num_cus() {
   return cached;
 }
 
-// MSDA_BWD_IMPL=generic forces the atomic kernel (A/B measurements); default picks by shape.
-bool tiled_allowed() {
-  const char *e = getenv("MSDA_BWD_IMPL");
-  return !(e && strcmp(e, "generic") == 0);
-}
-
 template <typename T>
 int backward_atomic(const char *who, const T *value, const int64_t *shapes, const int64_t *lsi,
                     const T *loc, const T *aw, const T *grad_out, int N, int S, int M, int D,
@@ -1115,27 +1678,139 @@ int launch_backward_tiled(const char *who, const VT *value, const int64_t *shape
   return check_launch(who);
 }
 
-template <>
-int backward_impl<float>(const char *who, const float *value, const int64_t *shapes,
-                         const int64_t *lsi, const float *loc, const float *aw,
-                         const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
-                         float *grad_value, float *grad_loc, float *grad_aw, void *stream) {
+// ---- binned backward: shape test, workspace size, launches ----
+bool binned_shape(int N, int S, int M, int D, int L, int Lq, int P) {
+  if (!(D == 32 && P <= binned::MAXP && L <= binned::MAXL && N > 0 && S > 0 && Lq > 0)) return false;
+  const size_t npairs = (size_t)N * Lq * M, limit = (size_t)1 << 30;
+  return (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit && npairs * D < limit &&
+         (size_t)N * Lq < ((size_t)1 << 28) &&                                   // entry = pair-less id << 4 | mask
+         npairs * L * binned::MAX_ENTRIES_PER_QUAD < ((size_t)1 << 32);         // 32-bit list positions
+}
+
+// uint32 words: counters[key_cap + 1], list starts[key_cap + 1], entries[16 * quads];
+// key_cap: one list per (image, head, tile), and a level has at most H*W tiles.
+size_t binned_key_cap(int N, int S, int M) { return (size_t)N * M * S; }
+size_t binned_workspace_bytes(int N, int S, int M, int L, int Lq, int P) {
+  (void)P;
+  const size_t words = 2 * (binned_key_cap(N, S, M) + 1) +
+                       (size_t)binned::MAX_ENTRIES_PER_QUAD * N * Lq * M * L;
+  return (words * 4 + 255) & ~(size_t)255;
+}
+
+template <typename VT>
+int launch_backward_binned(const char *who, const VT *value, const int64_t *shapes,
+                           const int64_t *lsi, const float *loc, const float *aw,
+                           const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
+                           float *grad_value, float *grad_loc, float *grad_aw, void *workspace,
+                           size_t workspace_bytes, hipStream_t st) {
+  const size_t need = binned_workspace_bytes(N, S, M, L, Lq, P);
+  if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 3u))
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "%s: needs a 4-byte aligned device workspace of at least %zu bytes (got %zu)", who,
+                need, workspace ? workspace_bytes : (size_t)0);
+  const uint32_t key_cap = (uint32_t)binned_key_cap(N, S, M);
+  uint32_t *counts = static_cast<uint32_t *>(workspace);
+  uint32_t *offs = counts + (size_t)key_cap + 1;
+  uint32_t *entries = offs + (size_t)key_cap + 1;
+  const uint32_t spi = (uint32_t)((size_t)Lq * M * L);          // quads per image
+  const uint32_t bpi = (spi + binned::BIN_QB - 1) / binned::BIN_QB;
+  const int cus = num_cus();
+  hipLaunchKernelGGL(binned::msda_bwd_bin_zero_kernel, dim3(cus), dim3(256), 0, st, shapes, N, M, L,
+                     key_cap, counts);
+  if (int rc = check_launch(who)) return rc;
+  hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<false>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
+                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, entries, grad_loc,
+                     grad_aw);
+  if (int rc = check_launch(who)) return rc;
+  hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, N, M, L,
+                     key_cap, counts, offs);
+  if (int rc = check_launch(who)) return rc;
+  hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<true>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
+                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, entries, grad_loc,
+                     grad_aw);
+  if (int rc = check_launch(who)) return rc;
+  hipLaunchKernelGGL(binned::msda_bwd_binned_kernel<VT>, dim3(2 * cus), dim3(binned::NT), 0, st,
+                     grad_out, value, shapes, lsi, loc, aw, offs, entries, key_cap, N, S, M, L, P,
+                     grad_value, grad_loc, grad_aw);
+  return check_launch(who);
+}
+
+// Which D == 32 backward: "binned" (default), "tiled" (round-1 candidate-rectangle kernels,
+// kept for A/B measurements), "generic" (atomics).
+int bwd_impl_choice() {
+  const char *e = getenv("MSDA_BWD_IMPL");
+  if (e && strcmp(e, "generic") == 0) return 0;
+  if (e && strcmp(e, "tiled") == 0) return 1;
+  return 2;
+}
+
+// Workspace from the device's stream-ordered pool when the caller brought none.
+struct PoolWorkspace {
+  void *ptr = nullptr;
+  hipStream_t st;
+  explicit PoolWorkspace(hipStream_t s) : st(s) {}
+  int get(const char *who, size_t bytes) {
+    const hipError_t e = hipMallocAsync(&ptr, bytes, st);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return fail(MSDA_ERR_LAUNCH, "%s: hipMallocAsync(%zu) failed: %s", who, bytes, hipGetErrorString(e));
+    }
+    return MSDA_OK;
+  }
+  ~PoolWorkspace() {
+    if (ptr) (void)hipFreeAsync(ptr, st);
+  }
+};
+
+template <typename VT>
+int backward_d32(const char *who, const VT *value, const int64_t *shapes, const int64_t *lsi,
+                 const float *loc, const float *aw, const VT *grad_out, int N, int S, int M, int L,
+                 int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw, void *workspace,
+                 size_t workspace_bytes, bool own_workspace, hipStream_t st) {
+  if (bwd_impl_choice() == 1 && P == tiled::P && Lq == S)
+    return launch_backward_tiled<VT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L,
+                                     grad_value, grad_loc, grad_aw, st);
+  if (!own_workspace)
+    return launch_backward_binned<VT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
+                                      grad_value, grad_loc, grad_aw, workspace, workspace_bytes, st);
+  PoolWorkspace pool(st);
+  const size_t need = binned_workspace_bytes(N, S, M, L, Lq, P);
+  if (int rc = pool.get(who, need)) return rc;
+  return launch_backward_binned<VT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
+                                    grad_value, grad_loc, grad_aw, pool.ptr, need, st);
+}
+
+int backward_f32(const char *who, const float *value, const int64_t *shapes, const int64_t *lsi,
+                 const float *loc, const float *aw, const float *grad_out, int N, int S, int M, int D,
+                 int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw,
+                 void *workspace, size_t workspace_bytes, bool own_workspace, void *stream) {
   if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t npairs = (size_t)N * Lq * M;
-  const size_t limit = (size_t)1 << 30;
-  const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit;
-  // Encoder self-attention shape (one query per pixel of every level): destination-tiled
-  // kernels.  The caller guarantees sum(H_l * W_l) == S, as the reference requires for memory
-  // safety (ops/modules/ms_deform_attn.py:96).
-  if (D == 32 && P == tiled::P && Lq == S && Lq > 0 && N > 0 && L <= tiled::MAXL && small &&
-      aligned16(value) && aligned16(grad_out) && aligned16(grad_value) && aligned16(loc) &&
-      aligned16(grad_loc) && tiled_allowed()) {
-    return launch_backward_tiled<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L,
-                                        grad_value, grad_loc, grad_aw, st);
-  }
+  if (binned_shape(N, S, M, D, L, Lq, P) && aligned16(value) && aligned16(grad_out) &&
+      aligned16(grad_value) && aligned16(loc) && aligned16(grad_loc) && bwd_impl_choice() != 0)
+    return backward_d32<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
+                               grad_value, grad_loc, grad_aw, workspace, workspace_bytes,
+                               own_workspace, st);
   return backward_atomic<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P,
                                 grad_value, grad_loc, grad_aw, st);
+}
+
+int backward_bf16(const char *who, const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                  const float *loc, const float *aw, const uint16_t *grad_out, int N, int S, int M,
+                  int D, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw,
+                  void *workspace, size_t workspace_bytes, bool own_workspace, void *stream) {
+  if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
+  if (!binned_shape(N, S, M, D, L, Lq, P) || (reinterpret_cast<uintptr_t>(value) & 7u) ||
+      (reinterpret_cast<uintptr_t>(grad_out) & 7u) || !aligned16(grad_value) || !aligned16(loc) ||
+      !aligned16(grad_loc))
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "%s: needs channels == 32, num_point <= %d, num_levels <= %d, a non-empty batch and "
+                "aligned tensors of < 2^30 elements",
+                who, binned::MAXP, binned::MAXL);
+  return backward_d32<bf16_t>(who, reinterpret_cast<const bf16_t *>(value), shapes, lsi, loc, aw,
+                              reinterpret_cast<const bf16_t *>(grad_out), N, S, M, L, Lq, P,
+                              grad_value, grad_loc, grad_aw, workspace, workspace_bytes,
+                              own_workspace, static_cast<hipStream_t>(stream));
 }
 
 }  // namespace
@@ -1152,7 +1827,7 @@ int msda_debug_phase_cycles(unsigned long long *out16) {
 }
 #endif
 
-int msda_abi_version(void) { return 1; }
+int msda_abi_version(void) { return 2; }
 
 const char *msda_last_error(void) { return g_err; }
 
@@ -1184,10 +1859,31 @@ int msda_backward_f32(const float *value, const int64_t *spatial_shapes,
                       int spatial_size, int num_heads, int channels, int num_levels,
                       int num_query, int num_point, float *grad_value, float *grad_sampling_loc,
                       float *grad_attn_weight, void *stream) {
-  return backward_impl<float>("msda_backward_f32", value, spatial_shapes, level_start_index,
-                              sampling_loc, attn_weight, grad_output, batch, spatial_size,
-                              num_heads, channels, num_levels, num_query, num_point, grad_value,
-                              grad_sampling_loc, grad_attn_weight, stream);
+  return backward_f32("msda_backward_f32", value, spatial_shapes, level_start_index, sampling_loc,
+                      attn_weight, grad_output, batch, spatial_size, num_heads, channels, num_levels,
+                      num_query, num_point, grad_value, grad_sampling_loc, grad_attn_weight, nullptr,
+                      0, true, stream);
+}
+
+int msda_backward_f32_ws(const float *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start_index, const float *sampling_loc,
+                         const float *attn_weight, const float *grad_output, int batch,
+                         int spatial_size, int num_heads, int channels, int num_levels,
+                         int num_query, int num_point, float *grad_value, float *grad_sampling_loc,
+                         float *grad_attn_weight, void *workspace, size_t workspace_bytes,
+                         void *stream) {
+  return backward_f32("msda_backward_f32_ws", value, spatial_shapes, level_start_index, sampling_loc,
+                      attn_weight, grad_output, batch, spatial_size, num_heads, channels, num_levels,
+                      num_query, num_point, grad_value, grad_sampling_loc, grad_attn_weight,
+                      workspace, workspace_bytes, false, stream);
+}
+
+size_t msda_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                     int num_levels, int num_query, int num_point) {
+  if (!binned_shape(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point) ||
+      bwd_impl_choice() == 0)
+    return 0;
+  return binned_workspace_bytes(batch, spatial_size, num_heads, num_levels, num_query, num_point);
 }
 
 int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
@@ -1217,23 +1913,23 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                        int spatial_size, int num_heads, int channels, int num_levels,
                        int num_query, int num_point, float *grad_value, float *grad_sampling_loc,
                        float *grad_attn_weight, void *stream) {
-  const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels,
-            Lq = num_query, P = num_point;
-  if (int rc = check_dims("msda_backward_bf16", N, S, M, D, L, Lq, P)) return rc;
-  const size_t npairs = (size_t)N * Lq * M, limit = (size_t)1 << 30;
-  const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit;
-  if (!(D == 32 && P == tiled::P && Lq == S && Lq > 0 && N > 0 && L <= tiled::MAXL && small) ||
-      (reinterpret_cast<uintptr_t>(value) & 7u) || (reinterpret_cast<uintptr_t>(grad_output) & 7u) ||
-      !aligned16(grad_value) || !aligned16(sampling_loc) || !aligned16(grad_sampling_loc))
-    return fail(MSDA_ERR_INVALID_ARGUMENT,
-                "msda_backward_bf16: needs the encoder shape (channels == 32, num_point == 4, "
-                "num_query == spatial_size, num_levels <= %d) and aligned tensors of < 2^30 elements",
-                tiled::MAXL);
-  return launch_backward_tiled<bf16_t>("msda_backward_bf16", reinterpret_cast<const bf16_t *>(value),
-                                       spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                       reinterpret_cast<const bf16_t *>(grad_output), N, S, M, L,
-                                       grad_value, grad_sampling_loc, grad_attn_weight,
-                                       static_cast<hipStream_t>(stream));
+  return backward_bf16("msda_backward_bf16", value, spatial_shapes, level_start_index, sampling_loc,
+                       attn_weight, grad_output, batch, spatial_size, num_heads, channels,
+                       num_levels, num_query, num_point, grad_value, grad_sampling_loc,
+                       grad_attn_weight, nullptr, 0, true, stream);
+}
+
+int msda_backward_bf16_ws(const uint16_t *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start_index, const float *sampling_loc,
+                          const float *attn_weight, const uint16_t *grad_output, int batch,
+                          int spatial_size, int num_heads, int channels, int num_levels,
+                          int num_query, int num_point, float *grad_value, float *grad_sampling_loc,
+                          float *grad_attn_weight, void *workspace, size_t workspace_bytes,
+                          void *stream) {
+  return backward_bf16("msda_backward_bf16_ws", value, spatial_shapes, level_start_index,
+                       sampling_loc, attn_weight, grad_output, batch, spatial_size, num_heads,
+                       channels, num_levels, num_query, num_point, grad_value, grad_sampling_loc,
+                       grad_attn_weight, workspace, workspace_bytes, false, stream);
 }
 
 int msda_backward_f64(const double *value, const int64_t *spatial_shapes,

@@ -42,10 +42,16 @@ def _load():
         b.argtypes, b.restype = bwd_args, _I
     lib.msda_forward_bf16.argtypes, lib.msda_forward_bf16.restype = fwd_args, _I
     lib.msda_backward_bf16.argtypes, lib.msda_backward_bf16.restype = bwd_args, _I
+    ws_args = [_P] * 6 + [_I] * 7 + [_P] * 4 + [ctypes.c_size_t, _P]
+    for suffix in ("f32", "bf16"):
+        b = getattr(lib, "msda_backward_%s_ws" % suffix)
+        b.argtypes, b.restype = ws_args, _I
+    lib.msda_backward_workspace_bytes.argtypes = [_I] * 7
+    lib.msda_backward_workspace_bytes.restype = ctypes.c_size_t
     lib.msda_last_error.restype = ctypes.c_char_p
     lib.msda_launch_count.restype = ctypes.c_uint64
     lib.msda_abi_version.restype = _I
-    if lib.msda_abi_version() != 1:
+    if lib.msda_abi_version() != 2:
         raise RuntimeError("libmsda_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -146,11 +152,19 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_sampling_loc = torch.empty_like(sampling_loc)
         grad_attn_weight = torch.empty_like(attn_weight)
         stream = torch.cuda.current_stream().cuda_stream
-        rc = getattr(lib, "msda_backward_" + _SUFFIX[value.dtype])(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
-            n, s, m, d, nl, lq, npt, grad_value.data_ptr(), grad_sampling_loc.data_ptr(),
-            grad_attn_weight.data_ptr(), stream)
+        args = (value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                n, s, m, d, nl, lq, npt, grad_value.data_ptr(), grad_sampling_loc.data_ptr(),
+                grad_attn_weight.data_ptr())
+        if value.dtype == torch.float64:
+            rc = lib.msda_backward_f64(*args, stream)
+        else:
+            # the sort-by-destination-tile workspace comes from torch's caching allocator
+            # (the library's own entry points without _ws use the HIP stream-ordered pool)
+            nbytes = int(lib.msda_backward_workspace_bytes(n, s, m, d, nl, lq, npt))
+            workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=value.device)
+            rc = getattr(lib, "msda_backward_%s_ws" % _SUFFIX[value.dtype])(
+                *args, workspace.data_ptr(), nbytes, stream)
     if rc != 0:
         _raise(lib, "ms_deform_attn_backward")
     return [grad_value, grad_sampling_loc, grad_attn_weight]
