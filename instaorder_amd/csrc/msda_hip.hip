@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     int N, int S, int M, int L, int P, float *__restrict__ grad_value,
     float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
   __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
-  __shared__ float4 s_go[CE * 8];           // grad_output rows of this chunk's entries
+  __shared__ float4 s_go[(CE + 1) * 8];     // grad_output rows of this chunk's entries + a zero row
   __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (entry slot, weight bits)
   __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
   __shared__ uint32_t s_q[CE];              // n*Lq + q of each slot of the chunk
@@ -1223,6 +1223,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
 
   const int tid = threadIdx.x;
   if (tid == 0) load_levels(lv, shapes, lsi, L);
+  if (tid < 8) s_go[CE * 8 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);     // what padding records read
   __syncthreads();
   const uint32_t I_img = (uint32_t)uni(lv.toff[L]) * (uint32_t)M;
   if ((uint64_t)N * I_img > key_cap) return;
@@ -1298,8 +1299,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       if (eidx(c, gslot + 64u) < total) g1 = ldrow4(grad_out, ((r1 >> 4) * (uint32_t)M + m) * 128u + gsub * 16u);
     };
 
-    // Software pipeline: ids two chunks ahead, (location, weight) and grad_output rows one ahead.
-    uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0, nn_ent = 0, nn_r0 = 0, nn_r1 = 0;
+    // Software pipeline: ids, (location, weight) and grad_output rows of the next chunk are
+    // requested while the current one is processed.
+    uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0;
     float2 c_xy = make_float2(0.f, 0.f);
     float c_a = 0.f;
     float4 c_g0 = make_float4(0.f, 0.f, 0.f, 0.f), c_g1 = c_g0;
@@ -1317,8 +1319,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       const int par = (int)(chunk & 1u);
       bool own1 = false, own2 = false, own3 = false, own4 = false, home = false;
       int r1 = 0;
-      float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-      float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);   // lh, lw, attn, packed geometry
 #ifdef MSDA_PHASE_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       MSDA_STAMP(8)
@@ -1334,19 +1335,13 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
         own3 = g.ok3 && yin1 && xin0;
         own4 = g.ok4 && yin1 && xin1;
         r1 = ly0 * T + lx0;
-        w1 = g.k1 * a;
-        w2 = g.k2 * a;
-        w3 = g.k3 * a;
-        w4 = g.k4 * a;
         const int hy = max(g.h0, 0) - y0, hx = max(g.w0, 0) - x0;
         home = g.in && (unsigned)hy < (unsigned)th && (unsigned)hx < (unsigned)tw;
-        if (home) {
-          const uint32_t ok = (g.ok1 ? 1u : 0u) | (g.ok2 ? 2u : 0u) | (g.ok3 ? 4u : 0u) |
-                              (g.ok4 ? 8u : 0u);
-          const uint32_t pk = (uint32_t)(ly0 + 1) | ((uint32_t)(lx0 + 1) << 5) | (ok << 10) |
-                              ((uint32_t)tid << 14);
-          hrec = make_float4(g.lh, g.lw, a, __uint_as_float(pk));
-        }
+        const uint32_t ok = (g.ok1 ? 1u : 0u) | (g.ok2 ? 2u : 0u) | (g.ok3 ? 4u : 0u) |
+                            (g.ok4 ? 8u : 0u);
+        const uint32_t pk = (uint32_t)(ly0 + 1) | ((uint32_t)(lx0 + 1) << 5) | (ok << 10) |
+                            ((uint32_t)tid << 14);
+        hrec = make_float4(g.lh, g.lw, a, __uint_as_float(pk));
       }
       MSDA_STAMP(9)
       const int dummy = TP + (tid & 63);
@@ -1356,7 +1351,6 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       const uint32_t pos4 = atomicAdd(&s_cnt[par][own4 ? r1 + T + 1 : dummy], 1u);
       MSDA_STAMP(10)
       if (chunk + 1u < nchunks) load_sample(n_ent, c_xy, c_a);               // consumed next chunk
-      if (chunk + 2u < nchunks) load_ids(chunk + 2u, nn_ent, nn_r0, nn_r1);
       {
         const uint32_t top = max(max(own1 ? pos1 : 0u, own2 ? pos2 : 0u),
                                  max(own3 ? pos3 : 0u, own4 ? pos4 : 0u));
@@ -1381,14 +1375,19 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t lo = r * (uint32_t)KB;
         if (r > 0) __syncthreads();                                     // previous round consumed
-        if (own1 && pos1 - lo < (uint32_t)KB)
-          s_rec[r1 * KB + (int)(pos1 - lo)] = make_uint2(slot, __float_as_uint(w1));
-        if (own2 && pos2 - lo < (uint32_t)KB)
-          s_rec[(r1 + 1) * KB + (int)(pos2 - lo)] = make_uint2(slot, __float_as_uint(w2));
-        if (own3 && pos3 - lo < (uint32_t)KB)
-          s_rec[(r1 + T) * KB + (int)(pos3 - lo)] = make_uint2(slot, __float_as_uint(w3));
-        if (own4 && pos4 - lo < (uint32_t)KB)
-          s_rec[(r1 + T + 1) * KB + (int)(pos4 - lo)] = make_uint2(slot, __float_as_uint(w4));
+        {
+          // corner weights (hh*hw, hh*lw, lh*hw, lh*lw) * attn, as corner_setup forms them
+          const float hh = 1.f - hrec.x, hw = 1.f - hrec.y;
+          const uint32_t rowb = slot * 128u;               // byte offset of the entry's row in s_go
+          if (own1 && pos1 - lo < (uint32_t)KB)
+            s_rec[r1 * KB + (int)(pos1 - lo)] = make_uint2(rowb, __float_as_uint(hh * hw * hrec.z));
+          if (own2 && pos2 - lo < (uint32_t)KB)
+            s_rec[(r1 + 1) * KB + (int)(pos2 - lo)] = make_uint2(rowb, __float_as_uint(hh * hrec.y * hrec.z));
+          if (own3 && pos3 - lo < (uint32_t)KB)
+            s_rec[(r1 + T) * KB + (int)(pos3 - lo)] = make_uint2(rowb, __float_as_uint(hrec.x * hw * hrec.z));
+          if (own4 && pos4 - lo < (uint32_t)KB)
+            s_rec[(r1 + T + 1) * KB + (int)(pos4 - lo)] = make_uint2(rowb, __float_as_uint(hrec.x * hrec.y * hrec.z));
+        }
         if (r == 0) {
           MSDA_STAMP(4)
         }
@@ -1397,23 +1396,34 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
           MSDA_STAMP(7)
         }
         // ---------------- phase D: every pixel's owners sum their bucket ----------------
+        // Four records per step, one 16-B piece of the four rows at a time, so the four row
+        // reads of a piece are in flight together and the next piece's overlap the FMAs.  The
+        // bucket is padded to a multiple of four with (zero row, weight 0) records: written by
+        // the pixel's first owner, read by both owners -- adjacent lanes of one wave, whose LDS
+        // operations execute in order.
         const int px = tid >> 1, half = tid & 1;
         const uint32_t cnt = s_cnt[par][px];
         const int nrec = (int)min(cnt > lo ? cnt - lo : 0u, (uint32_t)KB);
-        for (int i = 0; i < nrec; i += 2) {
-          const uint4 rr = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i]);
-          const bool two = i + 1 < nrec;
-          const int rowa = (int)rr.x, rowb = two ? (int)rr.z : 0;
-          const float wa = __uint_as_float(rr.y), wb = two ? __uint_as_float(rr.w) : 0.f;
+        if (half == 0)
+          for (int i = nrec; i < ((nrec + 3) & ~3); ++i) s_rec[px * KB + i] = make_uint2((uint32_t)CE * 128u, 0u);
+        __builtin_amdgcn_wave_barrier();
+        const char *gob = reinterpret_cast<const char *>(s_go);
+        for (int i = 0; i < nrec; i += 4) {
+          const uint4 ra = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i]);
+          const uint4 rb = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i + 2]);
+          const float w0 = __uint_as_float(ra.y), w1 = __uint_as_float(ra.w);
+          const float w2 = __uint_as_float(rb.y), w3 = __uint_as_float(rb.w);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int c = half * 4 + ((k + px) & 3);     // this lane's k-th chunk (see flush)
-            const float4 ga = s_go[rowa * 8 + c];
-            const float4 gb = s_go[rowb * 8 + c];
-            acc[k].x += wa * ga.x + wb * gb.x;
-            acc[k].y += wa * ga.y + wb * gb.y;
-            acc[k].z += wa * ga.z + wb * gb.z;
-            acc[k].w += wa * ga.w + wb * gb.w;
+            const uint32_t cb = (uint32_t)(half * 4 + ((k + px) & 3)) * 16u;   // this lane's k-th piece (see flush)
+            const float4 g0 = *reinterpret_cast<const float4 *>(gob + ra.x + cb);
+            const float4 g1 = *reinterpret_cast<const float4 *>(gob + ra.z + cb);
+            const float4 g2 = *reinterpret_cast<const float4 *>(gob + rb.x + cb);
+            const float4 g3 = *reinterpret_cast<const float4 *>(gob + rb.z + cb);
+            acc[k].x = fmaf(w3, g3.x, fmaf(w2, g2.x, fmaf(w1, g1.x, fmaf(w0, g0.x, acc[k].x))));
+            acc[k].y = fmaf(w3, g3.y, fmaf(w2, g2.y, fmaf(w1, g1.y, fmaf(w0, g0.y, acc[k].y))));
+            acc[k].z = fmaf(w3, g3.z, fmaf(w2, g2.z, fmaf(w1, g1.z, fmaf(w0, g0.z, acc[k].z))));
+            acc[k].w = fmaf(w3, g3.w, fmaf(w2, g2.w, fmaf(w1, g1.w, fmaf(w0, g0.w, acc[k].w))));
           }
         }
       }
@@ -1461,9 +1471,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       }
       MSDA_STAMP(6)
       c_ent = n_ent;
-      n_ent = nn_ent;
-      n_r0 = nn_r0;
-      n_r1 = nn_r1;
+      if (chunk + 2u < nchunks) load_ids(chunk + 2u, n_ent, n_r0, n_r1);     // used from the next chunk's phase A on
     }
     // ---------------- flush the tile's grad_value rows (sole owner: plain stores) ----------------
     {
