@@ -1202,6 +1202,18 @@ __global__ __launch_bounds__(1024) void msda_bwd_bin_scan_kernel(const int64_t *
   if (tid == 0) offs[nkeys] = carry;
 }
 
+// One work item of the tile kernel: a (image, level, tile, head) and its list.
+struct Item {
+  uint32_t n, m, list0, total, nchunks, lrow;   // lrow: value row of the level's first pixel
+  int l, H, W, y0, x0, th, tw;
+};
+
+struct Next {          // the part of an Item that fetching its chunks needs
+  uint32_t m;
+  int l;
+  uint32_t list0, total;
+};
+
 template <typename ST>
 __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     const ST *__restrict__ grad_out, const ST *__restrict__ value,
@@ -1212,111 +1224,125 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
   __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
   __shared__ float4 s_go[(CE + 1) * 8];     // grad_output rows of this chunk's entries + a zero row
-  __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (entry slot, weight bits)
+  __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (row byte offset in s_go, weight bits)
   __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
   __shared__ uint32_t s_q[CE];              // n*Lq + q of each slot of the chunk
   __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
   __shared__ uint32_t s_max[2];
   __shared__ uint32_t s_hcount[2];
-  __shared__ uint32_t s_list[2];
   __shared__ Levels lv;
 
   const int tid = threadIdx.x;
-  if (tid == 0) load_levels(lv, shapes, lsi, L);
+  if (tid == 0) {
+    load_levels(lv, shapes, lsi, L);
+    s_max[0] = s_max[1] = 0u;
+    s_hcount[0] = s_hcount[1] = 0u;
+  }
   if (tid < 8) s_go[CE * 8 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);     // what padding records read
+  for (int t = tid; t < 2 * (TP + 64); t += NT) (&s_cnt[0][0])[t] = 0;
   __syncthreads();
   const uint32_t I_img = (uint32_t)uni(lv.toff[L]) * (uint32_t)M;
   if ((uint64_t)N * I_img > key_cap) return;
   const uint32_t total_items = (uint32_t)N * I_img;
+  if (blockIdx.x >= total_items) return;
   MSDA_STAMP_DECL
 
   const uint32_t slot = (uint32_t)tid >> 2, p = (uint32_t)tid & 3u;      // exam: entry slot, point
   const uint32_t gslot = (uint32_t)tid >> 3, gsub = (uint32_t)tid & 7u;   // rows gslot, gslot + 64
 
-  for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
-    const uint32_t n = item / I_img, ri = item - n * I_img;
-    const uint32_t tl = ri / (uint32_t)M, m = ri - tl * (uint32_t)M;
+  auto decode = [&](uint32_t item) -> Item {
+    Item it;
+    it.n = item / I_img;
+    const uint32_t ri = item - it.n * I_img, tl = ri / (uint32_t)M;
+    it.m = ri - tl * (uint32_t)M;
     int l = 0;
     while (l + 1 < L && (int)tl >= uni(lv.toff[l + 1])) ++l;
-    const int H = uni(lv.H[l]), W = uni(lv.W[l]), ntx = uni(lv.ntx[l]);
-    const int tile = (int)tl - uni(lv.toff[l]);
+    it.l = l;
+    it.H = uni(lv.H[l]);
+    it.W = uni(lv.W[l]);
+    const int ntx = uni(lv.ntx[l]), tile = (int)tl - uni(lv.toff[l]);
     const int ty = tile / ntx, tx = tile - ty * ntx;
-    const int y0 = ty * T, x0 = tx * T;
-    const int th = min(T, H - y0), tw = min(T, W - x0);
+    it.y0 = ty * T;
+    it.x0 = tx * T;
+    it.th = min(T, it.H - it.y0);
+    it.tw = min(T, it.W - it.x0);
+    it.lrow = it.n * (uint32_t)S + (uint32_t)uni(lv.lsi[l]);
+    it.list0 = (uint32_t)uni((int)offs[item]);
+    it.total = (uint32_t)uni((int)offs[item + 1u]) - it.list0;
+    // an empty list still takes one (empty) chunk: the item has to store its zero rows anyway
+    it.nchunks = max((it.total + (uint32_t)CE - 1u) / (uint32_t)CE, 1u);
+    return it;
+  };
+  // what fetching a chunk needs to know of its item
+  auto peek = [&](uint32_t item) -> Next {
+    Next nx;
+    const uint32_t ri = item % I_img, tl = ri / (uint32_t)M;
+    nx.m = ri - tl * (uint32_t)M;
+    int l = 0;
+    while (l + 1 < L && (int)tl >= uni(lv.toff[l + 1])) ++l;
+    nx.l = l;
+    nx.list0 = (uint32_t)uni((int)offs[item]);
+    nx.total = (uint32_t)uni((int)offs[item + 1u]) - nx.list0;
+    return nx;
+  };
+  // entries of chunk `c` this thread needs: its exam slot and the two rows it stages
+  auto load_ids = [&](const Next &it, uint32_t c, uint32_t &ent, uint32_t &r0, uint32_t &r1) {
+    const uint32_t e = c * (uint32_t)CE + slot, e0 = c * (uint32_t)CE + gslot, e1 = e0 + 64u;
+    ent = e < it.total ? entries[it.list0 + e] : 0u;       // mask 0: nothing to examine
+    r0 = e0 < it.total ? entries[it.list0 + e0] : 0u;
+    r1 = e1 < it.total ? entries[it.list0 + e1] : 0u;
+  };
+  auto load_sample = [&](const Next &it, uint32_t ent, float2 &xy, float &a) {
+    if ((ent >> p) & 1u) {
+      const uint32_t s = (((ent >> 4) * (uint32_t)M + it.m) * (uint32_t)L + (uint32_t)it.l) * (uint32_t)P + p;
+      xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
+      a = aw[s];
+    }
+  };
+  auto load_rows = [&](const Next &it, uint32_t c, uint32_t r0, uint32_t r1, float4 &g0, float4 &g1) {
+    const uint32_t e0 = c * (uint32_t)CE + gslot;
+    if (e0 < it.total) g0 = ldrow4(grad_out, ((r0 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u);
+    if (e0 + 64u < it.total) g1 = ldrow4(grad_out, ((r1 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u);
+  };
 
-    if (tid == 0) {
-      s_list[0] = offs[item];
-      s_list[1] = offs[item + 1u];
-      s_hcount[0] = 0;
-      s_hcount[1] = 0;
-      s_max[0] = 0;
-      s_max[1] = 0;
-    }
-    // value tile -> LDS (zeros outside the level), counters cleared
-    {
-      const uint32_t lrow = n * (uint32_t)S + (uint32_t)uni(lv.lsi[l]);
-      for (int t = tid; t < (ZROW + 1) * 8; t += NT) {
-        const int row = t >> 3, sub = t & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < ZROW) {
-          const int y = y0 + row / VT, x = x0 + row % VT;
-          if (y < H && x < W)
-            v = ldrow4(value, ((lrow + (uint32_t)(y * W + x)) * (uint32_t)M + m) * 128u +
-                                (uint32_t)sub * 16u);
-        }
-        s_vt[row * 8 + sub] = v;
-      }
-      for (int t = tid; t < 2 * (TP + 64); t += NT) (&s_cnt[0][0])[t] = 0;
-    }
+  // The block's items and their chunks form one stream.  While a chunk is processed the next
+  // one -- of this item or of the block's next item -- is fetched: its entry ids during phase
+  // A, its sample (location, weight) and grad_output rows from phase C on.
+  uint32_t item = blockIdx.x;
+  Item cur = decode(item);
+  uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0;
+  float2 c_xy = make_float2(0.f, 0.f);
+  float c_a = 0.f;
+  float4 c_g0 = make_float4(0.f, 0.f, 0.f, 0.f), c_g1 = c_g0;
+  {
+    const Next first = {cur.m, cur.l, cur.list0, cur.total};
+    uint32_t r0 = 0, r1 = 0;
+    load_ids(first, 0, c_ent, r0, r1);
+    load_sample(first, c_ent, c_xy, c_a);
+    load_rows(first, 0, r0, r1, c_g0, c_g1);
+  }
+  uint32_t gchunk = 0;                                   // chunks so far: parity of the counters
+  for (;;) {
+    const uint32_t nitem = item + gridDim.x;
+    const bool has_next = nitem < total_items;
+    Next nxt = {0u, 0, 0u, 0u};
+    if (has_next) nxt = peek(nitem);
+    const int H = cur.H, W = cur.W, y0 = cur.y0, x0 = cur.x0, th = cur.th, tw = cur.tw;
+    const uint32_t m = cur.m;
+    const int l = cur.l;
     float4 acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    MSDA_STAMP(0)   // item turnover
 
-    const uint32_t list0 = (uint32_t)uni((int)s_list[0]);
-    const uint32_t total = (uint32_t)uni((int)s_list[1]) - list0;
-    const uint32_t nchunks = (total + (uint32_t)CE - 1u) / (uint32_t)CE;
-    auto eidx = [&](uint32_t c, uint32_t j) -> uint32_t { return c * (uint32_t)CE + j; };
-    // entries of chunk `c` this thread needs: its exam slot and the two rows it stages
-    auto load_ids = [&](uint32_t c, uint32_t &ent, uint32_t &r0, uint32_t &r1) {
-      const uint32_t e = eidx(c, slot), e0 = eidx(c, gslot), e1 = eidx(c, gslot + 64u);
-      ent = e < total ? entries[list0 + e] : 0u;          // mask 0: nothing to examine
-      if (e0 < total) r0 = entries[list0 + e0];
-      if (e1 < total) r1 = entries[list0 + e1];
-    };
-    auto sample_of = [&](uint32_t ent) -> uint32_t {
-      return (((ent >> 4) * (uint32_t)M + m) * (uint32_t)L + (uint32_t)l) * (uint32_t)P + p;
-    };
-    auto load_sample = [&](uint32_t ent, float2 &xy, float &a) {
-      if ((ent >> p) & 1u) {
-        const uint32_t s = sample_of(ent);
-        xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
-        a = aw[s];
-      }
-    };
-    auto load_rows = [&](uint32_t c, uint32_t r0, uint32_t r1, float4 &g0, float4 &g1) {
-      if (eidx(c, gslot) < total) g0 = ldrow4(grad_out, ((r0 >> 4) * (uint32_t)M + m) * 128u + gsub * 16u);
-      if (eidx(c, gslot + 64u) < total) g1 = ldrow4(grad_out, ((r1 >> 4) * (uint32_t)M + m) * 128u + gsub * 16u);
-    };
-
-    // Software pipeline: ids, (location, weight) and grad_output rows of the next chunk are
-    // requested while the current one is processed.
-    uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0;
-    float2 c_xy = make_float2(0.f, 0.f);
-    float c_a = 0.f;
-    float4 c_g0 = make_float4(0.f, 0.f, 0.f, 0.f), c_g1 = c_g0;
-    if (nchunks > 0) {
-      uint32_t r0 = 0, r1 = 0;
-      load_ids(0, c_ent, r0, r1);
-      if (nchunks > 1) load_ids(1, n_ent, n_r0, n_r1);
-      load_sample(c_ent, c_xy, c_a);
-      load_rows(0, r0, r1, c_g0, c_g1);
-    }
-    MSDA_STAMP(0)   // item setup
-
-    for (uint32_t chunk = 0; chunk < nchunks; ++chunk) {
+    for (uint32_t chunk = 0; chunk < cur.nchunks; ++chunk, ++gchunk) {
+      const int par = (int)(gchunk & 1u);
+      const bool last = chunk + 1u == cur.nchunks;
+      const bool nvalid = !last || has_next;             // there is a next chunk to fetch
+      const Next ni = last ? nxt : Next{cur.m, cur.l, cur.list0, cur.total};
+      const uint32_t nc = last ? 0u : chunk + 1u;
+      if (nvalid) load_ids(ni, nc, n_ent, n_r0, n_r1);
       // ---------------- phase A: examine one point of one list entry per thread ----------------
-      const int par = (int)(chunk & 1u);
       bool own1 = false, own2 = false, own3 = false, own4 = false, home = false;
       int r1 = 0;
       float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);   // lh, lw, attn, packed geometry
@@ -1344,13 +1370,14 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
         hrec = make_float4(g.lh, g.lw, a, __uint_as_float(pk));
       }
       MSDA_STAMP(9)
+      // Bucket positions: four unconditional, independent LDS atomics (corners the tile does
+      // not own count into a per-lane dummy), so their latencies overlap.
       const int dummy = TP + (tid & 63);
       const uint32_t pos1 = atomicAdd(&s_cnt[par][own1 ? r1 : dummy], 1u);
       const uint32_t pos2 = atomicAdd(&s_cnt[par][own2 ? r1 + 1 : dummy], 1u);
       const uint32_t pos3 = atomicAdd(&s_cnt[par][own3 ? r1 + T : dummy], 1u);
       const uint32_t pos4 = atomicAdd(&s_cnt[par][own4 ? r1 + T + 1 : dummy], 1u);
       MSDA_STAMP(10)
-      if (chunk + 1u < nchunks) load_sample(n_ent, c_xy, c_a);               // consumed next chunk
       {
         const uint32_t top = max(max(own1 ? pos1 : 0u, own2 ? pos2 : 0u),
                                  max(own3 ? pos3 : 0u, own4 ? pos4 : 0u));
@@ -1362,8 +1389,31 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       // ---------------- phase C: contributions -> pixel buckets; rows, home list -> LDS ----------------
       s_go[gslot * 8u + gsub] = c_g0;
       s_go[(gslot + 64u) * 8u + gsub] = c_g1;
-      if (chunk + 1u < nchunks) load_rows(chunk + 1u, n_r0, n_r1, c_g0, c_g1);
       if (p == 0u) s_q[slot] = c_ent >> 4;
+      if (chunk == 0) {
+        // The item's value tile (zeros outside the level).  fp32 rows go global -> LDS directly
+        // (one 1-KiB wave-instruction per 64 consecutive pieces, no registers, all five in
+        // flight at once); the barrier below waits for them.
+#pragma unroll 1
+        for (int j = 0; j < 5; ++j) {
+          const int t = tid + j * NT, row = t >> 3, sub = t & 7;
+          if (t < (ZROW + 1) * 8) {
+            const int y = y0 + row / VT, x = x0 + row % VT;
+            const bool inl = row < ZROW && y < H && x < W;
+            const uint32_t off = ((cur.lrow + (uint32_t)(y * W + x)) * (uint32_t)M + m) * 128u + (uint32_t)sub * 16u;
+            if constexpr (sizeof(ST) == 4) {
+              if (inl)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(value) + off),
+                    (__attribute__((address_space(3))) void *)(&s_vt[t - (tid & 63)]), 16, 0, 0);   // wave base: lane i lands 16*i further
+              else
+                s_vt[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+              s_vt[t] = inl ? ldrow4(value, off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+        }
+      }
       if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
       for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
       if (tid == 0) {
@@ -1394,6 +1444,11 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
         __syncthreads();
         if (r == 0) {
           MSDA_STAMP(7)
+          if (nvalid) {                                   // consumed by the next chunk
+            load_sample(ni, n_ent, c_xy, c_a);
+            load_rows(ni, nc, n_r0, n_r1, c_g0, c_g1);
+          }
+          c_ent = n_ent;
         }
         // ---------------- phase D: every pixel's owners sum their bucket ----------------
         // Four records per step, one 16-B piece of the four rows at a time, so the four row
@@ -1429,6 +1484,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       }
       MSDA_STAMP(5)
       // ---------------- phase E: gradients of the samples this tile is home to ----------------
+      // Two lanes per sample, 16 channels each: dot the staged grad_output row with the four
+      // corner rows of the LDS value tile, pair-sum with one DPP step, lane 0 finishes.
       {
         const uint32_t hc = (uint32_t)uni((int)s_hcount[par]);
         const int half = tid & 1;
@@ -1470,15 +1527,13 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
         }
       }
       MSDA_STAMP(6)
-      c_ent = n_ent;
-      if (chunk + 2u < nchunks) load_ids(chunk + 2u, n_ent, n_r0, n_r1);     // used from the next chunk's phase A on
     }
-    // ---------------- flush the tile's grad_value rows (sole owner: plain stores) ----------------
+    // ---------------- the tile's grad_value rows (sole owner: plain stores) ----------------
     {
       const int px = tid >> 1, half = tid & 1;
       const int py = px / T, pxx = px % T;
       if (py < th && pxx < tw) {
-        const uint32_t rowi = n * (uint32_t)S + (uint32_t)uni(lv.lsi[l]) + (uint32_t)((y0 + py) * W + x0 + pxx);
+        const uint32_t rowi = cur.lrow + (uint32_t)((y0 + py) * W + x0 + pxx);
         float4 *dst = reinterpret_cast<float4 *>(
             reinterpret_cast<char *>(grad_value) +
             ((size_t)(rowi * (uint32_t)M + m) * 128u + (size_t)half * 64u));
@@ -1486,8 +1541,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
         for (int k = 0; k < 4; ++k) dst[(k + px) & 3] = acc[k];
       }
     }
-    __syncthreads();
-    MSDA_STAMP(0)
+    if (!has_next) break;
+    item = nitem;
+    cur = decode(item);
   }
   MSDA_STAMP_FLUSH
 }
