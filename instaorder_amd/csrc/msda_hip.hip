@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void msda_bwd_far_kernel(
 //                               gate-closed samples,
 //   msda_bwd_binned_kernel      the tile kernel.
 // Workspace (caller-provided), uint32 words: counters[key_cap + 1], starts[key_cap + 1],
-// entries[16 * quads]; key_cap = N*M*S >= number of lists (a level has at most H*W tiles), and
+// descriptors[quads], entries[16 * quads]; key_cap = N*M*S >= number of lists (a level has at most H*W tiles), and
 // a quad touches at most 16 tiles (typically 1-2: the bound is address space, not traffic).
 // =======================================================================================
 namespace binned {
@@ -1061,11 +1061,19 @@ __device__ __forceinline__ void for_each_entry(const PointTiles (&pt)[4], F &&f)
   }
 }
 
+// What the counting pass learnt about a quad, kept for the scatter pass (one uint32 per quad):
+// bit 31 clear: the quad spans at most 2 x 2 tiles; bits 0-14 hold the first tile's index in
+// its level, bits 15-30 the four 4-bit point masks of tiles (0,0), (0,1), (1,0), (1,1); a
+// point in none of them is gate-closed.  Bit 31 set: look at the locations again.
+constexpr uint32_t DESC_SLOW = 1u << 31;
+constexpr int DESC_MAX_TILE = 1 << 15;
+
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_NT) void msda_bwd_bin_kernel(
     const int64_t *__restrict__ shapes, const float *__restrict__ loc, int N, int M, int L, int Lq,
     int P, uint32_t qpi, uint32_t bpi, uint32_t key_cap, uint32_t *__restrict__ counts,
-    uint32_t *__restrict__ entries, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
+    uint32_t *__restrict__ desc, uint32_t *__restrict__ entries, float *__restrict__ grad_loc,
+    float *__restrict__ grad_aw) {
   __shared__ uint32_t s_hist[KCAP];
   __shared__ Levels lv;
   const int tid = threadIdx.x;
@@ -1079,12 +1087,14 @@ __global__ __launch_bounds__(BIN_NT) void msda_bwd_bin_kernel(
   const uint32_t ML = (uint32_t)(M * L);
   const uint32_t q0 = n * qpi;                          // first quad of this image
 
-  // quad i of the image -> its points' tiles; returns the quad's (query, head, level)
-  auto examine = [&](uint32_t i, PointTiles (&pt)[4], uint32_t &q, uint32_t &m, uint32_t &l) {
+  auto decode = [&](uint32_t i, uint32_t &q, uint32_t &m, uint32_t &l) {
     q = i / ML;
     const uint32_t r = i - q * ML;
     m = r / (uint32_t)L;
     l = r - m * (uint32_t)L;
+  };
+  // quad i of the image -> its points' tiles
+  auto examine = [&](uint32_t i, uint32_t l, PointTiles (&pt)[4]) {
     const int H = lv.H[l], W = lv.W[l];
     const float *lp = loc + 2u * (q0 + i) * (uint32_t)P;
     if (P == 4) {
@@ -1105,56 +1115,134 @@ __global__ __launch_bounds__(BIN_NT) void msda_bwd_bin_kernel(
       }
     }
   };
+  // f(list key within the image, point mask) for every list of a quad described by `d`
+  auto for_each_fast = [&](uint32_t d, uint32_t m, uint32_t l, auto &&f) {
+    const uint32_t t0 = (uint32_t)lv.toff[l] + (d & (uint32_t)(DESC_MAX_TILE - 1)), ntx = (uint32_t)lv.ntx[l];
+    const uint32_t m00 = (d >> 15) & 15u, m01 = (d >> 19) & 15u, m10 = (d >> 23) & 15u, m11 = (d >> 27) & 15u;
+    if (m00) f(t0 * (uint32_t)M + m, m00);
+    if (m01) f((t0 + 1u) * (uint32_t)M + m, m01);
+    if (m10) f((t0 + ntx) * (uint32_t)M + m, m10);
+    if (m11) f((t0 + ntx + 1u) * (uint32_t)M + m, m11);
+  };
+  auto for_each_slow = [&](uint32_t i, uint32_t m, uint32_t l, uint32_t &closed, auto &&f) {
+    PointTiles pt[4];
+    examine(i, l, pt);
+    const int toff = lv.toff[l], ntx = lv.ntx[l];
+    closed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < P && !pt[j].in) closed |= 1u << j;
+    for_each_entry(pt, [&](int ty, int tx, uint32_t mask) {
+      f((uint32_t)(toff + ty * ntx + tx) * (uint32_t)M + m, mask);
+    });
+  };
+  auto bump = [&](uint32_t key, uint32_t) {
+    if (use_lds)
+      atomicAdd(&s_hist[key], 1u);
+    else
+      atomicAdd(&counts[gk0 + key], 1u);
+  };
 
   if (use_lds) {
     for (uint32_t k = tid; k < keys_img; k += BIN_NT) s_hist[k] = 0u;
     __syncthreads();
   }
-  if (use_lds || !SCATTER) {
+  if (!SCATTER) {
+    // counting pass: look at the locations, describe the quad, count its lists
     for (int r = 0; r < BIN_QPT; ++r) {
       const uint32_t i = base + (uint32_t)(r * BIN_NT + tid);
       if (i >= qpi) continue;
-      PointTiles pt[4];
       uint32_t q, m, l;
-      examine(i, pt, q, m, l);
-      const int toff = lv.toff[l], ntx = lv.ntx[l];
-      for_each_entry(pt, [&](int ty, int tx, uint32_t) {
-        const uint32_t key = (uint32_t)(toff + ty * ntx + tx) * (uint32_t)M + m;
-        if (use_lds)
-          atomicAdd(&s_hist[key], 1u);
-        else
-          atomicAdd(&counts[gk0 + key], 1u);
-      });
+      decode(i, q, m, l);
+      PointTiles pt[4];
+      examine(i, l, pt);
+      int tymin = 1 << 30, tymax = -1, txmin = 1 << 30, txmax = -1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (pt[j].in) {
+          tymin = min(tymin, pt[j].tya);
+          tymax = max(tymax, pt[j].tyb);
+          txmin = min(txmin, pt[j].txa);
+          txmax = max(txmax, pt[j].txb);
+        }
+      uint32_t d = 0;
+      if (tymax >= 0) {
+        const int ntx = lv.ntx[l], t0 = tymin * ntx + txmin;
+        if (tymax - tymin <= 1 && txmax - txmin <= 1 && t0 < DESC_MAX_TILE) {
+          d = (uint32_t)t0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (pt[j].in) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const int ty = tymin + (c >> 1), tx = txmin + (c & 1);
+                if ((ty == pt[j].tya || ty == pt[j].tyb) && (tx == pt[j].txa || tx == pt[j].txb))
+                  d |= 1u << (15 + 4 * c + j);
+              }
+            }
+          for_each_fast(d, m, l, bump);
+        } else {
+          d = DESC_SLOW;
+          const int toff = lv.toff[l];
+          for_each_entry(pt, [&](int ty, int tx, uint32_t mask) {
+            bump((uint32_t)(toff + ty * ntx + tx) * (uint32_t)M + m, mask);
+          });
+        }
+      }
+      desc[q0 + i] = d;
     }
+    if (use_lds) {
+      __syncthreads();
+      for (uint32_t k = tid; k < keys_img; k += BIN_NT) {
+        const uint32_t c = s_hist[k];
+        if (c) atomicAdd(&counts[gk0 + k], c);
+      }
+    }
+    return;
   }
+  // scatter pass: per-workgroup counts again (from the descriptors), one reservation per list
+  // in the global cursors, then the entries
   if (use_lds) {
+    for (int r = 0; r < BIN_QPT; ++r) {
+      const uint32_t i = base + (uint32_t)(r * BIN_NT + tid);
+      if (i >= qpi) continue;
+      const uint32_t d = desc[q0 + i];
+      if (d == 0u) continue;
+      uint32_t q, m, l, closed;
+      decode(i, q, m, l);
+      if (d & DESC_SLOW)
+        for_each_slow(i, m, l, closed, bump);
+      else
+        for_each_fast(d, m, l, bump);
+    }
     __syncthreads();
     for (uint32_t k = tid; k < keys_img; k += BIN_NT) {
       const uint32_t c = s_hist[k];
-      if (c) {
-        const uint32_t old = atomicAdd(&counts[gk0 + k], c);   // SCATTER: counts holds the cursors
-        if (SCATTER) s_hist[k] = old;
-      }
+      if (c) s_hist[k] = atomicAdd(&counts[gk0 + k], c);   // counts holds the cursors by now
     }
+    __syncthreads();
   }
-  if (!SCATTER) return;
-  __syncthreads();
   for (int r = 0; r < BIN_QPT; ++r) {
     const uint32_t i = base + (uint32_t)(r * BIN_NT + tid);
     if (i >= qpi) continue;
-    PointTiles pt[4];
+    const uint32_t d = desc[q0 + i];
     uint32_t q, m, l;
-    examine(i, pt, q, m, l);
-    const int toff = lv.toff[l], ntx = lv.ntx[l];
+    decode(i, q, m, l);
     const uint32_t ent = (n * (uint32_t)Lq + q) << 4;
-    for_each_entry(pt, [&](int ty, int tx, uint32_t mask) {
-      const uint32_t key = (uint32_t)(toff + ty * ntx + tx) * (uint32_t)M + m;
+    auto put = [&](uint32_t key, uint32_t mask) {
       const uint32_t pos = use_lds ? atomicAdd(&s_hist[key], 1u) : atomicAdd(&counts[gk0 + key], 1u);
       entries[pos] = ent | mask;
-    });
+    };
+    uint32_t closed;
+    if (d & DESC_SLOW) {
+      for_each_slow(i, m, l, closed, put);
+    } else {
+      for_each_fast(d, m, l, put);
+      closed = ~((d >> 15) | (d >> 19) | (d >> 23) | (d >> 27)) & ((1u << P) - 1u);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < P && !pt[j].in) {                          // gate closed: zero gradients
+      if ((closed >> j) & 1u) {                            // gate closed: zero gradients
         const uint32_t s = (q0 + i) * (uint32_t)P + (uint32_t)j;
         grad_aw[s] = 0.f;
         *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2(0.f, 0.f);
@@ -1751,13 +1839,13 @@ bool binned_shape(int N, int S, int M, int D, int L, int Lq, int P) {
          npairs * L * binned::MAX_ENTRIES_PER_QUAD < ((size_t)1 << 32);         // 32-bit list positions
 }
 
-// uint32 words: counters[key_cap + 1], list starts[key_cap + 1], entries[16 * quads];
+// uint32 words: counters[key_cap + 1], list starts[key_cap + 1], descriptors[quads], entries[16 * quads];
 // key_cap: one list per (image, head, tile), and a level has at most H*W tiles.
 size_t binned_key_cap(int N, int S, int M) { return (size_t)N * M * S; }
 size_t binned_workspace_bytes(int N, int S, int M, int L, int Lq, int P) {
   (void)P;
   const size_t words = 2 * (binned_key_cap(N, S, M) + 1) +
-                       (size_t)binned::MAX_ENTRIES_PER_QUAD * N * Lq * M * L;
+                       (size_t)(1 + binned::MAX_ENTRIES_PER_QUAD) * N * Lq * M * L;
   return (words * 4 + 255) & ~(size_t)255;
 }
 
@@ -1775,7 +1863,8 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
   const uint32_t key_cap = (uint32_t)binned_key_cap(N, S, M);
   uint32_t *counts = static_cast<uint32_t *>(workspace);
   uint32_t *offs = counts + (size_t)key_cap + 1;
-  uint32_t *entries = offs + (size_t)key_cap + 1;
+  uint32_t *desc = offs + (size_t)key_cap + 1;
+  uint32_t *entries = desc + (size_t)N * Lq * M * L;
   const uint32_t spi = (uint32_t)((size_t)Lq * M * L);          // quads per image
   const uint32_t bpi = (spi + binned::BIN_QB - 1) / binned::BIN_QB;
   const int cus = num_cus();
@@ -1783,15 +1872,15 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
                      key_cap, counts);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<false>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, entries, grad_loc,
-                     grad_aw);
+                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, desc, entries,
+                     grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, N, M, L,
                      key_cap, counts, offs);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<true>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, entries, grad_loc,
-                     grad_aw);
+                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, desc, entries,
+                     grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_binned_kernel<VT>, dim3(2 * cus), dim3(binned::NT), 0, st,
                      grad_out, value, shapes, lsi, loc, aw, offs, entries, key_cap, N, S, M, L, P,
