@@ -1001,6 +1001,7 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_zero_kernel(const int64_t *_
                                                                 int N, int M, int L, uint32_t key_cap,
                                                                 uint32_t *__restrict__ counts) {
   const uint64_t nkeys = count_lists(shapes, N, M, L);
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[(size_t)key_cap + 1] = 0u;   // the tile kernel's work counter
   if (nkeys > key_cap) return;
   for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k <= nkeys; k += (uint64_t)gridDim.x * 256u)
     counts[k] = 0u;
@@ -1307,9 +1308,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     const ST *__restrict__ grad_out, const ST *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ aw,
-    const uint32_t *__restrict__ offs, const uint32_t *__restrict__ entries, uint32_t key_cap,
-    int N, int S, int M, int L, int P, float *__restrict__ grad_value,
-    float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
+    const uint32_t *__restrict__ offs, const uint32_t *__restrict__ entries,
+    uint32_t *__restrict__ work, uint32_t key_cap, int N, int S, int M, int L, int P,
+    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
   __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
   __shared__ float4 s_go[(CE + 1) * 8];     // grad_output rows of this chunk's entries + a zero row
   __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (row byte offset in s_go, weight bits)
@@ -1318,6 +1319,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
   __shared__ uint32_t s_max[2];
   __shared__ uint32_t s_hcount[2];
+  __shared__ uint32_t s_pos[2];             // queue positions handed out to this workgroup
+  __shared__ int s_ord[MAXL], s_pbase[MAXL + 1];
   __shared__ Levels lv;
 
   const int tid = threadIdx.x;
@@ -1325,6 +1328,25 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     load_levels(lv, shapes, lsi, L);
     s_max[0] = s_max[1] = 0u;
     s_hcount[0] = s_hcount[1] = 0u;
+    // Work queue order: levels by ascending tile count.  Every level receives the same number
+    // of samples, so the tiles of a coarse level carry the longest lists; handing those out
+    // first lets the light tiles of the fine levels even out the tail.
+    for (int i = 0; i < L; ++i) s_ord[i] = i;
+    for (int i = 1; i < L; ++i)
+      for (int j = i; j > 0; --j) {
+        const int a = s_ord[j - 1], b = s_ord[j];
+        if (lv.toff[b + 1] - lv.toff[b] < lv.toff[a + 1] - lv.toff[a]) {
+          s_ord[j - 1] = b;
+          s_ord[j] = a;
+        }
+      }
+    int pb = 0;
+    for (int i = 0; i < L; ++i) {
+      s_pbase[i] = pb;
+      pb += N * M * (lv.toff[s_ord[i] + 1] - lv.toff[s_ord[i]]);
+    }
+    s_pbase[L] = pb;
+    s_pos[0] = gridDim.x + atomicAdd(work, 1u);          // this workgroup's second item
   }
   if (tid < 8) s_go[CE * 8 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);     // what padding records read
   for (int t = tid; t < 2 * (TP + 64); t += NT) (&s_cnt[0][0])[t] = 0;
@@ -1338,6 +1360,16 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   const uint32_t slot = (uint32_t)tid >> 2, p = (uint32_t)tid & 3u;      // exam: entry slot, point
   const uint32_t gslot = (uint32_t)tid >> 3, gsub = (uint32_t)tid & 7u;   // rows gslot, gslot + 64
 
+  // queue position -> item index (the numbering of the lists: image, level, tile, head)
+  auto item_at = [&](uint32_t pos) -> uint32_t {
+    int j = 0;
+    while (j + 1 < L && (int)pos >= uni(s_pbase[j + 1])) ++j;
+    const int l = uni(s_ord[j]);
+    const uint32_t r = pos - (uint32_t)uni(s_pbase[j]);
+    const uint32_t per = (uint32_t)(uni(lv.toff[l + 1]) - uni(lv.toff[l])) * (uint32_t)M;   // items per image
+    const uint32_t n = r / per;
+    return n * I_img + (uint32_t)uni(lv.toff[l]) * (uint32_t)M + (r - n * per);
+  };
   auto decode = [&](uint32_t item) -> Item {
     Item it;
     it.n = item / I_img;
@@ -1396,8 +1428,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   // The block's items and their chunks form one stream.  While a chunk is processed the next
   // one -- of this item or of the block's next item -- is fetched: its entry ids during phase
   // A, its sample (location, weight) and grad_output rows from phase C on.
-  uint32_t item = blockIdx.x;
-  Item cur = decode(item);
+  uint32_t pos = blockIdx.x, npos = (uint32_t)uni((int)s_pos[0]);
+  Item cur = decode(item_at(pos));
   uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0;
   float2 c_xy = make_float2(0.f, 0.f);
   float c_a = 0.f;
@@ -1410,11 +1442,14 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     load_rows(first, 0, r0, r1, c_g0, c_g1);
   }
   uint32_t gchunk = 0;                                   // chunks so far: parity of the counters
-  for (;;) {
-    const uint32_t nitem = item + gridDim.x;
-    const bool has_next = nitem < total_items;
+  for (uint32_t k = 0;; ++k) {
+    // position of the item after the next one: asked for now, published in phase C of this
+    // item's first chunk, read by everyone when this item is done
+    uint32_t fetched = 0;
+    if (tid == 0) fetched = gridDim.x + atomicAdd(work, 1u);
+    const bool has_next = npos < total_items;
     Next nxt = {0u, 0, 0u, 0u};
-    if (has_next) nxt = peek(nitem);
+    if (has_next) nxt = peek(item_at(npos));
     const int H = cur.H, W = cur.W, y0 = cur.y0, x0 = cur.x0, th = cur.th, tw = cur.tw;
     const uint32_t m = cur.m;
     const int l = cur.l;
@@ -1502,6 +1537,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
           }
         }
       }
+      if (chunk == 0 && tid == 0) s_pos[(k + 1u) & 1u] = fetched;
       if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
       for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
       if (tid == 0) {
@@ -1630,8 +1666,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       }
     }
     if (!has_next) break;
-    item = nitem;
-    cur = decode(item);
+    pos = npos;
+    npos = (uint32_t)uni((int)s_pos[(k + 1u) & 1u]);
+    cur = decode(item_at(pos));
   }
   MSDA_STAMP_FLUSH
 }
@@ -1839,12 +1876,13 @@ bool binned_shape(int N, int S, int M, int D, int L, int Lq, int P) {
          npairs * L * binned::MAX_ENTRIES_PER_QUAD < ((size_t)1 << 32);         // 32-bit list positions
 }
 
-// uint32 words: counters[key_cap + 1], list starts[key_cap + 1], descriptors[quads], entries[16 * quads];
+// uint32 words: counters[key_cap + 1] + work counter, list starts[key_cap + 1] + pad, descriptors[quads],
+// entries[16 * quads];
 // key_cap: one list per (image, head, tile), and a level has at most H*W tiles.
 size_t binned_key_cap(int N, int S, int M) { return (size_t)N * M * S; }
 size_t binned_workspace_bytes(int N, int S, int M, int L, int Lq, int P) {
   (void)P;
-  const size_t words = 2 * (binned_key_cap(N, S, M) + 1) +
+  const size_t words = 2 * (binned_key_cap(N, S, M) + 2) +
                        (size_t)(1 + binned::MAX_ENTRIES_PER_QUAD) * N * Lq * M * L;
   return (words * 4 + 255) & ~(size_t)255;
 }
@@ -1862,8 +1900,9 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
                 need, workspace ? workspace_bytes : (size_t)0);
   const uint32_t key_cap = (uint32_t)binned_key_cap(N, S, M);
   uint32_t *counts = static_cast<uint32_t *>(workspace);
-  uint32_t *offs = counts + (size_t)key_cap + 1;
-  uint32_t *desc = offs + (size_t)key_cap + 1;
+  uint32_t *work = counts + (size_t)key_cap + 1;
+  uint32_t *offs = counts + (size_t)key_cap + 2;
+  uint32_t *desc = offs + (size_t)key_cap + 2;
   uint32_t *entries = desc + (size_t)N * Lq * M * L;
   const uint32_t spi = (uint32_t)((size_t)Lq * M * L);          // quads per image
   const uint32_t bpi = (spi + binned::BIN_QB - 1) / binned::BIN_QB;
@@ -1883,8 +1922,8 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
                      grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_binned_kernel<VT>, dim3(2 * cus), dim3(binned::NT), 0, st,
-                     grad_out, value, shapes, lsi, loc, aw, offs, entries, key_cap, N, S, M, L, P,
-                     grad_value, grad_loc, grad_aw);
+                     grad_out, value, shapes, lsi, loc, aw, offs, entries, work, key_cap, N, S, M, L,
+                     P, grad_value, grad_loc, grad_aw);
   return check_launch(who);
 }
 
