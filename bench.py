@@ -148,8 +148,8 @@ def main():
         bwd_b = (32 * 2 + 32 * 2 + 32 * 4) / 12 + 24
     else:
         fwd_b, bwd_b = synthetic.algorithmic_bytes_per_sample()
-    # dominant kernel = the backward call: msda_bwd_tiled_kernel (>90 % of it) followed by
-    # msda_bwd_far_kernel on the same stream; both are inside the event bracket
+    # dominant kernel = the backward call: the binning passes (zero, count, scan, scatter) and
+    # msda_bwd_binned_kernel (~89 % of it) on the same stream; all are inside the event bracket
     bwd_gbs = samples * bwd_b / (bwd_avg * 1e-3) / 1e9
     fwd_gbs = samples * fwd_b / (fwd_avg * 1e-3) / 1e9
     both_gbs = samples * (fwd_b + bwd_b) / ((fwd_avg + bwd_avg) * 1e-3) / 1e9
@@ -180,7 +180,7 @@ def main():
                                   "/".join("%dx%d" % s for s in shapes),
                                   sum(h * w for h, w in shapes), args.dist),
                    "samples_per_step_per_gpu": samples, "parallelism": "batch-sharded x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "msda_backward_f32 call = msda_bwd_tiled_kernel + msda_bwd_far_kernel",
+        "roofline": {"bound": "hbm", "kernel": "msda_backward call = msda_bwd_bin_{zero,count,scan,scatter} + msda_bwd_binned_kernel",
                      "achieved": round(bwd_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(bwd_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(samples * bwd_b),

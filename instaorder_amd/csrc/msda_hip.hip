@@ -60,8 +60,9 @@ struct Corner4 {
   bool ok1, ok2, ok3, ok4, in;
 };
 
-// loc * size - 0.5 as ONE fused multiply-add, so that every kernel (and both passes of the
-// tiled backward, which must agree on where a sample lands) gets bit-identical coordinates.
+// loc * size - 0.5 as ONE fused multiply-add, so that every kernel (and the binning pass and
+// the tile kernel of the backward, which must agree on where a sample lands) gets bit-identical
+// coordinates.
 __device__ __forceinline__ float pix_coord(float loc, float size) { return __fmaf_rn(loc, size, -0.5f); }
 __device__ __forceinline__ double pix_coord(double loc, double size) { return fma(loc, size, -0.5); }
 
@@ -150,11 +151,6 @@ __device__ __forceinline__ void strow4(bf16_t *__restrict__ base, uint32_t f32_o
   *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(base) + (f32_off >> 1)) =
       make_uint2(f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16), f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16));
 }
-__device__ __forceinline__ float ldval(const float *__restrict__ base, uint32_t idx) { return base[idx]; }
-__device__ __forceinline__ float ldval(const bf16_t *__restrict__ base, uint32_t idx) {
-  return bf16_to_f32(base[idx].bits);
-}
-
 // NS samples of one level: all 4*NS corner rows are requested before the first is used.
 template <typename VT, int NS>
 __device__ __forceinline__ void fwd_samples_d32(const VT *__restrict__ value, uint32_t lbyte,
@@ -339,42 +335,54 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
 }
 
 // =======================================================================================
-// Backward, fp32, D == 32, P == 4, encoder self-attention (Lq == S): destination-tiled.
+// Backward, fp32 arithmetic, D == 32, P <= 4, any Lq: *binned* destination-tiled backward.
+// Replaces ms_deformable_col2im_gpu_kernel_shm_blocksize_aware_reduce_v1<float, 32>
+// (ms_deform_im2col_cuda.cuh:306-408), the variant every InstaFormer config dispatches to.
 //
 // Why: scattering grad_value with global float atomics runs at the chip-wide atomic rate
 // (~1.35 TB/s measured: 12 ms for bs16 @1024^2), and LDS float atomics are no way out
 // (ds_add_f32 measured at ~185 cycles per wave-instruction on gfx950,
 // tools/microbench_lds_atomic.hip).  So grad_value is accumulated in REGISTERS, with no
-// float atomic anywhere on the common path:
+// float atomic anywhere:
 //
-//   * A work item is one (image n, head m, level l, 16x16-pixel tile of that level).  Its
+//   * A work item is one (image n, level l, 16x16-pixel tile of that level, head m).  Its
 //     workgroup owns those 256 grad_value rows: thread (pixel, half) keeps 16 channels of
 //     one pixel in registers for the whole item and stores them once at the end (plain,
 //     coalesced stores; grad_value needs no zero-fill).
-//   * In encoder self-attention query q sits at a pixel centre of one of the levels, and
-//     samples land near that point.  The workgroup examines every *candidate* sample --
-//     queries of any level whose nominal centre, mapped into level l, lies within NEAR_R+1
-//     pixels of the tile -- one sample per thread, in chunks of 128 queries x 4 points.
-//     A sample is *near* if it lands within NEAR_R pixels of its query's nominal centre; a
-//     near sample touching the tile is therefore always among the tile's candidates.
-//   * Per chunk: counting sort of the (corner -> pixel) contributions in LDS (integer LDS
-//     atomics only), grad_output rows of the queries that hit staged once in LDS, then
-//     every pixel's owner threads walk their pixel's list: acc += w * grad_output_row.
-//   * The tile that holds a near sample's top-left corner (its *home*) also computes that
-//     sample's grad_sampling_loc / grad_attn_weight: 8 lanes x 4 channels read the four
+//   * A counting sort hands every tile the list of the samples that touch it.  A list entry
+//     is one *quad* -- the (up to 4) points of one (image, query, head, level) -- plus a mask
+//     of the points that have at least one in-level corner inside the tile; a quad is listed
+//     once in every tile its points touch (model-like locations: 1.35 tiles per quad, 3.0 of
+//     4 points live per entry).  Any distribution of sampling locations and any Lq run
+//     through the same kernels.
+//   * The tile kernel takes its list in chunks of 128 entries, four threads (one per point)
+//     per entry.  Per chunk: counting sort of the (corner -> pixel) contributions in LDS
+//     (integer LDS atomics only), grad_output rows of the entries staged once in LDS, then
+//     every pixel's owner threads walk their pixel's bucket: acc += w * grad_output_row.
+//   * The tile that holds a sample's top-left in-level corner (its *home*) also computes that
+//     sample's grad_sampling_loc / grad_attn_weight: two lanes x 16 channels read the four
 //     corner rows from an LDS copy of the (T+1)^2 value tile and the staged grad_output row.
-//   * Samples whose gate is closed get their zero gradients from the tile holding their
-//     query's nominal centre.  Samples that are in range but NOT near (none for model-like
-//     inputs) are left to msda_bwd_far_kernel, which runs afterwards on the same stream and
-//     adds them with global atomics -- correctness never depends on where samples land.
+//   * Samples whose gate is closed get their zero gradients from the binning pass.
 //
-// Replaces ms_deformable_col2im_gpu_kernel_shm_blocksize_aware_reduce_v1<float, 32>
-// (ms_deform_im2col_cuda.cuh:306-408), the variant every InstaFormer config dispatches to.
+// Kernels, all on the caller's stream, all reading the level shapes on the device:
+//   msda_bwd_bin_zero_kernel    clears the per-list counters and the work counter,
+//   msda_bwd_bin_kernel<false>  looks at every location once: describes each quad (which of
+//                               <= 2x2 tiles its points touch) and counts entries per list --
+//                               LDS histogram per workgroup, one global atomic per touched list,
+//   msda_bwd_bin_scan_kernel    exclusive prefix sum -> list starts,
+//   msda_bwd_bin_kernel<true>   writes the entries to their lists (from the descriptors), and
+//                               the zero gradients of gate-closed samples,
+//   msda_bwd_binned_kernel      the tile kernel; workgroups take items from a queue ordered
+//                               coarse level first (their tiles carry the longest lists).
+// Workspace (caller-provided), uint32 words: counters[key_cap + 1], work counter,
+// starts[key_cap + 1], pad, descriptors[quads], entries[16 * quads]; key_cap = N*M*S >= number
+// of lists (a level has at most H*W tiles), and a quad touches at most 16 tiles (typically
+// 1-2: the bound is address space, not traffic).
 // =======================================================================================
-namespace tiled {
+namespace binned {
 
-// Diagnostic build only (-DMSDA_PHASE_STAMPS): per-phase shader-clock sums of the tiled
-// backward, accumulated per wave and added to a device array that no kernel reads.
+// Diagnostic build only (-DMSDA_PHASE_STAMPS): per-phase shader-clock sums of the tile kernel,
+// accumulated per wave and added to a device array that no kernel reads.
 #ifdef MSDA_PHASE_STAMPS
 __device__ unsigned long long g_phase_cycles[16];
 #define MSDA_STAMP_DECL unsigned long long st_last = clock64(), st_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -386,574 +394,13 @@ __device__ unsigned long long g_phase_cycles[16];
 #define MSDA_STAMP_FLUSH
 #endif
 
-constexpr int T = 16;             // tile side, pixels of the sampled level
-constexpr int TP = T * T;         // pixels per tile
-constexpr int VT = T + 1;         // value tile side (a home sample reaches one pixel further)
-constexpr int ZROW = VT * VT;     // all-zero row standing in for out-of-level corners
-constexpr int NT = 512;           // threads per workgroup (2 workgroups per CU by LDS)
-constexpr int P = 4;              // points per level on this path
-constexpr int CQ = NT / P;        // candidate queries per chunk: one sample per thread
-constexpr int MAXL = 8;
-constexpr int LATX = 16, LATY = CQ / LATX;   // query lattice of one chunk (LATX * LATY == CQ)
-constexpr int KB = 8;             // bucket depth: contributions per pixel per round
-constexpr float NEAR_R = 6.0f;    // pixels; see the near/far contract above
-
-// Nominal centre of query pixel `xq` (level of width Wq) in the coordinates of the sampled
-// level, given scale = W / Wq.  Explicitly rounded steps: both kernels must agree exactly.
-__device__ __forceinline__ float nominal_centre(int xq, float scale) {
-  return __fsub_rn(__fmul_rn((float)xq + 0.5f, scale), 0.5f);
-}
-__device__ __forceinline__ float level_scale(int W, int Wq) { return __fdiv_rn((float)W, (float)Wq); }
-
-__device__ __forceinline__ bool is_near(const Corner4<float> &g, float cx, float cy) {
-  return g.in && fabsf(g.w_im - cx) <= NEAR_R && fabsf(g.h_im - cy) <= NEAR_R;
-}
-
 // Workgroup-uniform values read from LDS land in VGPRs; pin them to scalar registers.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float unif(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
 
 // Sum over an aligned lane pair (quad permute [1,0,3,2]), in DPP: no LDS round trip.
 __device__ __forceinline__ float sum2(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
-
-template <typename ST>   // ST: storage type of value / grad_output (float or bf16_t)
-__global__ __launch_bounds__(NT, 4) void msda_bwd_tiled_kernel(
-    const ST *__restrict__ grad_out, const ST *__restrict__ value,
-    const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
-    const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int L,
-    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
-  __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
-  __shared__ float4 s_go[CQ * 8];           // grad_output rows of this chunk's queries
-  __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (query slot, weight bits)
-  __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
-  __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
-  __shared__ uint32_t s_max[2];             // highest bucket position (only set on overflow)
-  __shared__ uint32_t s_hcount[2];
-  __shared__ int s_H[MAXL], s_W[MAXL], s_lsi[MAXL], s_qoff[MAXL + 1], s_ioff[MAXL + 1];
-  __shared__ int s_cx0[MAXL], s_cy0[MAXL], s_cnx[MAXL], s_cny[MAXL], s_SX[MAXL], s_SY[MAXL];
-  __shared__ float s_sx[MAXL], s_sy[MAXL];
-
-  const int tid = threadIdx.x;
-  const uint32_t Lq = (uint32_t)S;
-  if (tid == 0) {
-    int qo = 0, io = 0;
-    for (int l = 0; l < L; ++l) {
-      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-      s_H[l] = H;
-      s_W[l] = W;
-      s_lsi[l] = (int)lsi[l];
-      s_qoff[l] = qo;
-      s_ioff[l] = io;
-      qo += H * W;
-      io += N * M * ((H + T - 1) / T) * ((W + T - 1) / T);
-    }
-    s_qoff[L] = qo;
-    s_ioff[L] = io;
-  }
-  __syncthreads();
-  const int total_items = uni(s_ioff[L]);
-  MSDA_STAMP_DECL
-
-  const int ql = tid >> 2, p = tid & 3;                 // exam: query slot, point
-  const int qi = ql & (LATX - 1), qj = ql / LATX;       // slot position in the query lattice
-  const int gslot = tid >> 3, gsub = tid & 7;           // grad_output rows: slots gslot, gslot+64
-
-  for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
-    int l = 0;
-    while (l + 1 < L && item >= uni(s_ioff[l + 1])) ++l;
-    const int H = uni(s_H[l]), W = uni(s_W[l]);
-    const int ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
-    const int rem = item - uni(s_ioff[l]);
-    const int tile = rem % (ntx * nty), nm = rem / (ntx * nty);
-    const int m = nm % M, n = nm / M;
-    const int y0 = (tile / ntx) * T, x0 = (tile % ntx) * T;
-    const int th = min(T, H - y0), tw = min(T, W - x0);
-
-    if (tid == 0) {
-      for (int lq = 0; lq < L; ++lq) {
-        const int Hq = s_H[lq], Wq = s_W[lq];
-        const float sx = level_scale(W, Wq), sy = level_scale(H, Hq);
-        s_sx[lq] = sx;
-        s_sy[lq] = sy;
-        // Queries whose nominal centre c satisfies  x0 - 1 - R <= c < x0 + tw + R : a near
-        // sample of any other query cannot have a corner inside the tile.  c = (xq+.5)*sx-.5;
-        // the 0.01 px slack dwarfs the rounding of that expression.
-        int xa = (int)floorf(((float)x0 - 0.51f - NEAR_R) / sx - 0.5f);
-        int xb = (int)ceilf(((float)(x0 + tw) + 0.51f + NEAR_R) / sx - 0.5f);
-        int ya = (int)floorf(((float)y0 - 0.51f - NEAR_R) / sy - 0.5f);
-        int yb = (int)ceilf(((float)(y0 + th) + 0.51f + NEAR_R) / sy - 0.5f);
-        xa = max(xa, 0);
-        ya = max(ya, 0);
-        xb = min(xb, Wq - 1);
-        yb = min(yb, Hq - 1);
-        const int nx = max(xb - xa + 1, 0), ny = max(yb - ya + 1, 0);
-        s_cx0[lq] = xa;
-        s_cy0[lq] = ya;
-        s_cnx[lq] = nx;
-        s_cny[lq] = (nx > 0) ? ny : 0;
-        // A chunk takes a LATX x LATY lattice of the rectangle with strides (SX, SY), so its
-        // samples spread over the whole tile and the per-pixel lists of a chunk stay short.
-        s_SX[lq] = max((nx + LATX - 1) / LATX, 1);
-        s_SY[lq] = max((ny + LATY - 1) / LATY, 1);
-      }
-      s_hcount[0] = 0;
-      s_hcount[1] = 0;
-      s_max[0] = 0;
-      s_max[1] = 0;
-    }
-    // value tile -> LDS (zeros outside the level), counters cleared
-    {
-      const uint32_t lrow = (uint32_t)n * (uint32_t)S + (uint32_t)uni(s_lsi[l]);
-      for (int t = tid; t < (ZROW + 1) * 8; t += NT) {
-        const int row = t >> 3, sub = t & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < ZROW) {
-          const int y = y0 + row / VT, x = x0 + row % VT;
-          if (y < H && x < W)
-            v = ldrow4(value, ((lrow + (uint32_t)(y * W + x)) * (uint32_t)M + (uint32_t)m) * 128u +
-                                (uint32_t)sub * 16u);
-        }
-        s_vt[row * 8 + sub] = v;
-      }
-      for (int t = tid; t < 2 * (TP + 64); t += NT) (&s_cnt[0][0])[t] = 0;
-    }
-    float4 acc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    // ---- candidate enumeration: (query level, lattice phase) -> one chunk ----
-    // `e` walks the chunks of this item; all of it is workgroup-uniform.  Slot (i, j) of a
-    // chunk is query (cx0 + phx + SX*i, cy0 + phy + SY*j) of level lq, valid while inside
-    // the candidate rectangle.
-    struct Enum {
-      int lq, phy, phx, SX, SY, nx, ny, cx0, cy0, Wq, qoff;
-      float sx, sy;
-    } e;
-    auto load_level = [&](int lq) {
-      while (lq < L && uni(s_cny[lq]) == 0) ++lq;
-      e.lq = lq;
-      e.phy = 0;
-      e.phx = 0;
-      if (lq < L) {
-        e.SX = uni(s_SX[lq]);
-        e.SY = uni(s_SY[lq]);
-        e.nx = uni(s_cnx[lq]);
-        e.ny = uni(s_cny[lq]);
-        e.cx0 = uni(s_cx0[lq]);
-        e.cy0 = uni(s_cy0[lq]);
-        e.Wq = uni(s_W[lq]);
-        e.qoff = uni(s_qoff[lq]);
-        e.sx = unif(s_sx[lq]);
-        e.sy = unif(s_sy[lq]);
-      }
-    };
-    auto advance = [&]() {
-      if (++e.phx == e.SX) {
-        e.phx = 0;
-        if (++e.phy == e.SY) load_level(e.lq + 1);
-      }
-    };
-    // Per-chunk uniforms of the chunk being consumed (phase E maps a slot back to its query).
-    int c_qorg = 0, c_SX = 0, c_SYW = 0;
-    // Software pipeline: the next chunk's sample (location, weight) and grad_output rows are
-    // requested during phase A of the current chunk and consumed one chunk later.
-    bool n_valid = false;
-    float n_cx = 0.f, n_cy = 0.f;
-    uint32_t n_s = 0;
-    float2 n_xy = make_float2(0.f, 0.f);
-    float n_a = 0.f;
-    float4 n_g0 = make_float4(0.f, 0.f, 0.f, 0.f), n_g1 = n_g0;
-    int n_qorg = 0, n_SX = 0, n_SY = 0, n_SYW = 0, n_vx = 0, n_vy = 0;
-    auto prefetch = [&]() {                               // for the chunk `e` points at
-      const int vx = e.nx - e.phx, vy = e.ny - e.phy;     // slot (i, j) valid iff SX*i < vx, SY*j < vy
-      n_SX = e.SX;
-      n_SY = e.SY;
-      n_SYW = e.SY * e.Wq;
-      n_qorg = e.qoff + (e.cy0 + e.phy) * e.Wq + e.cx0 + e.phx;
-      n_valid = e.SX * qi < vx && e.SY * qj < vy;
-      if (n_valid) {
-        const uint32_t q = (uint32_t)(n_qorg + qj * n_SYW + qi * n_SX);
-        n_cx = nominal_centre(e.cx0 + e.phx + e.SX * qi, e.sx);
-        n_cy = nominal_centre(e.cy0 + e.phy + e.SY * qj, e.sy);
-        const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
-        n_s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (uint32_t)p;
-        n_xy = *reinterpret_cast<const float2 *>(loc + 2u * n_s);
-        n_a = aw[n_s];
-      }
-      n_vx = vx;
-      n_vy = vy;
-    };
-    // grad_output rows of the chunk described by n_* (issued in phase C, once the previous
-    // rows have been handed to LDS, and consumed in phase C of the next chunk)
-    auto prefetch_rows = [&]() {
-      const int gi = gslot & (LATX - 1), gj = gslot / LATX;
-      if (n_SX * gi < n_vx && n_SY * gj < n_vy)
-        n_g0 = ldrow4(grad_out, (((uint32_t)n * Lq + (uint32_t)(n_qorg + gj * n_SYW + gi * n_SX)) *
-                                   (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
-      if (n_SX * gi < n_vx && n_SY * (gj + 64 / LATX) < n_vy)
-        n_g1 = ldrow4(grad_out, (((uint32_t)n * Lq +
-                                (uint32_t)(n_qorg + (gj + 64 / LATX) * n_SYW + gi * n_SX)) *
-                                   (uint32_t)M + (uint32_t)m) * 128u + (uint32_t)gsub * 16u);
-    };
-    load_level(0);
-    bool have = e.lq < L;                                 // a chunk has been prefetched
-    if (have) {
-      prefetch();
-      prefetch_rows();
-      advance();
-    }
-    MSDA_STAMP(0)   // item setup: value tile, candidate rectangles, first prefetch
-
-    for (int chunk = 0; have; ++chunk) {
-      // ---------------- phase A: examine one candidate sample per thread ----------------
-      const int par = chunk & 1;
-      bool own1 = false, own2 = false, own3 = false, own4 = false, home = false;
-      int r1 = 0;
-      float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-      float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef MSDA_PHASE_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      MSDA_STAMP(8)   // wait for the prefetched sample (and everything older)
-#endif
-      c_qorg = n_qorg;
-      c_SX = n_SX;
-      c_SYW = n_SYW;
-      if (n_valid) {
-        const uint32_t s = n_s;
-        const float a = n_a;
-        const Corner4<float> g = corner_setup<float>(n_xy.x, n_xy.y, H, W);
-        const float cx = n_cx, cy = n_cy;
-        if (!g.in) {
-          // gate closed: zero gradients, written by the tile holding the nominal centre
-          const int px = min(max((int)floorf(cx + 0.5f), 0), W - 1) - x0;
-          const int py = min(max((int)floorf(cy + 0.5f), 0), H - 1) - y0;
-          if ((unsigned)px < (unsigned)tw && (unsigned)py < (unsigned)th) {
-            grad_aw[s] = 0.f;
-            *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2(0.f, 0.f);
-          }
-        } else if (is_near(g, cx, cy)) {
-          const int ly0 = g.h0 - y0, lx0 = g.w0 - x0;       // corner 1 in tile coordinates
-          const bool yin0 = (unsigned)ly0 < (unsigned)th, yin1 = (unsigned)(ly0 + 1) < (unsigned)th;
-          const bool xin0 = (unsigned)lx0 < (unsigned)tw, xin1 = (unsigned)(lx0 + 1) < (unsigned)tw;
-          own1 = g.ok1 && yin0 && xin0;
-          own2 = g.ok2 && yin0 && xin1;
-          own3 = g.ok3 && yin1 && xin0;
-          own4 = g.ok4 && yin1 && xin1;
-          r1 = ly0 * T + lx0;
-          w1 = g.k1 * a;
-          w2 = g.k2 * a;
-          w3 = g.k3 * a;
-          w4 = g.k4 * a;
-          const int hy = max(g.h0, 0) - y0, hx = max(g.w0, 0) - x0;
-          home = (unsigned)hy < (unsigned)th && (unsigned)hx < (unsigned)tw;
-          if (home) {
-            const uint32_t ok = (g.ok1 ? 1u : 0u) | (g.ok2 ? 2u : 0u) | (g.ok3 ? 4u : 0u) |
-                                (g.ok4 ? 8u : 0u);
-            const uint32_t pk = (uint32_t)(ly0 + 1) | ((uint32_t)(lx0 + 1) << 5) | (ok << 10) |
-                                ((uint32_t)tid << 14);
-            hrec = make_float4(g.lh, g.lw, a, __uint_as_float(pk));
-          }
-        }
-      }
-      MSDA_STAMP(9)   // phase A: geometry
-      // Bucket positions: four unconditional, independent LDS atomics (corners the tile does
-      // not own count into a per-lane dummy), so their latencies overlap.
-      const int dummy = TP + (tid & 63);
-      const uint32_t pos1 = atomicAdd(&s_cnt[par][own1 ? r1 : dummy], 1u);
-      const uint32_t pos2 = atomicAdd(&s_cnt[par][own2 ? r1 + 1 : dummy], 1u);
-      const uint32_t pos3 = atomicAdd(&s_cnt[par][own3 ? r1 + T : dummy], 1u);
-      const uint32_t pos4 = atomicAdd(&s_cnt[par][own4 ? r1 + T + 1 : dummy], 1u);
-      MSDA_STAMP(10)  // phase A: atomics issue
-      have = e.lq < L;
-      if (have) {
-        prefetch();
-        advance();
-      }
-      {
-        const uint32_t top = max(max(own1 ? pos1 : 0u, own2 ? pos2 : 0u),
-                                 max(own3 ? pos3 : 0u, own4 ? pos4 : 0u));
-        if (top >= (uint32_t)KB) atomicMax(&s_max[par], top);   // rare: a bucket overflowed
-      }
-      MSDA_STAMP(1)   // phase A
-      __syncthreads();   // every wave is past phases D/E of the previous chunk
-      MSDA_STAMP(2)   // barrier 1
-      // ---------------- phase C: contributions -> pixel buckets; rows, home list -> LDS ----------------
-      s_go[gslot * 8 + gsub] = n_g0;
-      s_go[(gslot + 64) * 8 + gsub] = n_g1;
-      if (have) prefetch_rows();                         // rows of the chunk after this one
-      if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
-      for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
-      if (tid == 0) {
-        s_hcount[par ^ 1] = 0u;
-        s_max[par ^ 1] = 0u;
-      }
-      const uint32_t rounds = (uint32_t)uni((int)s_max[par]) / (uint32_t)KB + 1u;          // 1 unless a bucket overflowed
-      MSDA_STAMP(3)   // phase C: rows to LDS, home push, zeroing, row prefetch
-      for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t lo = r * (uint32_t)KB;
-        if (r > 0) __syncthreads();                                     // previous round consumed
-        if (own1 && pos1 - lo < (uint32_t)KB)
-          s_rec[r1 * KB + (int)(pos1 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w1));
-        if (own2 && pos2 - lo < (uint32_t)KB)
-          s_rec[(r1 + 1) * KB + (int)(pos2 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w2));
-        if (own3 && pos3 - lo < (uint32_t)KB)
-          s_rec[(r1 + T) * KB + (int)(pos3 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w3));
-        if (own4 && pos4 - lo < (uint32_t)KB)
-          s_rec[(r1 + T + 1) * KB + (int)(pos4 - lo)] = make_uint2((uint32_t)ql, __float_as_uint(w4));
-        if (r == 0) {
-          MSDA_STAMP(4)   // phase C: scatter
-        }
-        __syncthreads();
-        if (r == 0) {
-          MSDA_STAMP(7)   // barrier 2
-        }
-        // ---------------- phase D: every pixel's owners sum their bucket ----------------
-        // Two records per step (a record past the end of the list is a copy of slot 0 with
-        // weight 0), so eight row reads are in flight before the FMAs start.
-        const int px = tid >> 1, half = tid & 1;
-        const uint32_t cnt = s_cnt[par][px];
-        const int nrec = (int)min(cnt > lo ? cnt - lo : 0u, (uint32_t)KB);
-        for (int i = 0; i < nrec; i += 2) {
-          const uint4 rr = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i]);
-          const bool two = i + 1 < nrec;
-          const int rowa = (int)rr.x, rowb = two ? (int)rr.z : 0;
-          const float wa = __uint_as_float(rr.y), wb = two ? __uint_as_float(rr.w) : 0.f;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int c = half * 4 + ((k + px) & 3);     // this lane's k-th chunk (see flush)
-            const float4 ga = s_go[rowa * 8 + c];
-            const float4 gb = s_go[rowb * 8 + c];
-            acc[k].x += wa * ga.x + wb * gb.x;
-            acc[k].y += wa * ga.y + wb * gb.y;
-            acc[k].z += wa * ga.z + wb * gb.z;
-            acc[k].w += wa * ga.w + wb * gb.w;
-          }
-        }
-      }
-      MSDA_STAMP(5)   // phase D
-      // ---------------- phase E: gradients of the samples this tile is home to ----------------
-      // Two lanes per sample, 16 channels each: dot the staged grad_output row with the four
-      // corner rows of the LDS value tile, pair-sum with one DPP step, lane 0 finishes.
-      {
-        const uint32_t hc = (uint32_t)uni((int)s_hcount[par]);
-        const int half = tid & 1;
-        for (uint32_t h = (uint32_t)tid >> 1; h < hc; h += NT / 2) {
-          const float4 hr = s_home[h];
-          const uint32_t pk = __float_as_uint(hr.w);
-          const int by = (int)(pk & 31u) - 1, bx = (int)((pk >> 5) & 31u) - 1;
-          const uint32_t ok = (pk >> 10) & 15u, e = pk >> 14;
-          const int slot = (int)(e >> 2);
-          const int rb = by * VT + bx;
-          const int ra = (ok & 1u) ? rb : ZROW, rbb = (ok & 2u) ? rb + 1 : ZROW;
-          const int rc = (ok & 4u) ? rb + VT : ZROW, rd = (ok & 8u) ? rb + VT + 1 : ZROW;
-          float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int c = half * 4 + ((k + (int)h) & 3);
-            const float4 g4 = s_go[slot * 8 + c];
-            const float4 v1 = s_vt[ra * 8 + c];
-            const float4 v2 = s_vt[rbb * 8 + c];
-            const float4 v3 = s_vt[rc * 8 + c];
-            const float4 v4 = s_vt[rd * 8 + c];
-            d1 += g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w;
-            d2 += g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w;
-            d3 += g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w;
-            d4 += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
-          }
-          d1 = sum2(d1);
-          d2 = sum2(d2);
-          d3 = sum2(d3);
-          d4 = sum2(d4);
-          if (half == 0) {
-            const float lh = hr.x, lw = hr.y, a = hr.z, hh = 1.f - lh, hw = 1.f - lw;
-            const uint32_t q = (uint32_t)(c_qorg + (slot / LATX) * c_SYW + (slot & (LATX - 1)) * c_SX);
-            const uint32_t pair = ((uint32_t)n * Lq + q) * (uint32_t)M + (uint32_t)m;
-            const uint32_t s = (pair * (uint32_t)L + (uint32_t)l) * 4u + (e & 3u);
-            grad_aw[s] = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
-            const float gw = (float)W * a * (hh * (d2 - d1) + lh * (d4 - d3));
-            const float gh = (float)H * a * (hw * (d3 - d1) + lw * (d4 - d2));
-            *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2(gw, gh);
-          }
-        }
-      }
-      MSDA_STAMP(6)   // phase E
-    }
-    // ---------------- flush the tile's grad_value rows (sole owner: plain stores) ----------------
-    {
-      const int px = tid >> 1, half = tid & 1;
-      const int py = px / T, pxx = px % T;
-      if (py < th && pxx < tw) {
-        const uint32_t rowi = (uint32_t)n * (uint32_t)S + (uint32_t)uni(s_lsi[l]) +
-                              (uint32_t)((y0 + py) * W + x0 + pxx);
-        float4 *dst = reinterpret_cast<float4 *>(
-            reinterpret_cast<char *>(grad_value) +
-            ((size_t)(rowi * (uint32_t)M + (uint32_t)m) * 128u + (size_t)half * 64u));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dst[(k + px) & 3] = acc[k];
-      }
-    }
-    __syncthreads();
-    MSDA_STAMP(0)
-  }
-  MSDA_STAMP_FLUSH
-}
-
-// ---------------------------------------------------------------------------------------
-// Second pass of the tiled backward: samples that are in range but not *near* their
-// query's nominal centre (see above).  One lane scans the L*4 samples of one pair (its
-// locations are 96 contiguous bytes); the wave then takes the far samples found two at a
-// time (one per half-wave, lane = channel) and treats them like the generic kernel: hardware float atomics into grad_value (which the first pass has
-// fully written by then -- same stream), shuffle-reduced grad_sampling_loc/grad_attn_weight.
-// Every sample is scanned (sampling_loc is re-read once); nothing to do when all are near.
-// ---------------------------------------------------------------------------------------
-template <typename ST>
-__global__ __launch_bounds__(256) void msda_bwd_far_kernel(
-    const ST *__restrict__ grad_out, const ST *__restrict__ value,
-    const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
-    const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int L,
-    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
-  __shared__ int s_H[MAXL], s_W[MAXL], s_lsi[MAXL], s_qoff[MAXL + 1];
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) {
-    int qo = 0;
-    for (int l = 0; l < L; ++l) {
-      s_H[l] = (int)shapes[2 * l];
-      s_W[l] = (int)shapes[2 * l + 1];
-      s_lsi[l] = (int)lsi[l];
-      s_qoff[l] = qo;
-      qo += s_H[l] * s_W[l];
-    }
-    s_qoff[L] = qo;
-  }
-  __syncthreads();
-  const uint32_t Lq = (uint32_t)S;
-  const uint32_t npairs = (uint32_t)N * Lq * (uint32_t)M;
-  const uint32_t stride = gridDim.x * 256u;
-  const uint32_t nrounds = (npairs + stride - 1u) / stride;
-  for (uint32_t round = 0; round < nrounds; ++round) {
-    // ---- scan: one lane examines the L*4 samples of one pair; bit (l*4+p) of farmask = far ----
-    const uint32_t pair = round * stride + blockIdx.x * 256u + (uint32_t)tid;
-    uint32_t farmask = 0;
-    if (pair < npairs) {
-      const uint32_t q = (pair / (uint32_t)M) % Lq;
-      int lq = 0;
-      while (lq + 1 < L && (int)q >= s_qoff[lq + 1]) ++lq;
-      const int Wq = s_W[lq], Hq = s_H[lq];
-      const int qq = (int)q - s_qoff[lq];
-      const int yq = qq / Wq, xq = qq - yq * Wq;
-      for (int l = 0; l < L; ++l) {
-        const int H = s_H[l], W = s_W[l];
-        const float cx = nominal_centre(xq, level_scale(W, Wq));
-        const float cy = nominal_centre(yq, level_scale(H, Hq));
-        const uint32_t s0 = (pair * (uint32_t)L + (uint32_t)l) * 4u;
-        const float4 xa = ld16(loc, s0 * 8u), xb = ld16(loc, s0 * 8u + 16u);
-        const float lx[4] = {xa.x, xa.z, xb.x, xb.z}, ly[4] = {xa.y, xa.w, xb.y, xb.w};
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float w_im = pix_coord(lx[p], (float)W), h_im = pix_coord(ly[p], (float)H);
-          const bool in = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-          const bool near = fabsf(w_im - cx) <= NEAR_R && fabsf(h_im - cy) <= NEAR_R;
-          if (in && !near) farmask |= 1u << (l * 4 + p);
-        }
-      }
-    }
-    // ---- process: far samples two at a time, one per half-wave, lane = channel ----
-    // The lower half takes the first (lane, bit) still pending, the upper half the last one.
-    for (;;) {
-      const unsigned long long pending = __ballot(farmask != 0u);
-      if (!pending) break;
-      const int la = __ffsll((long long)pending) - 1;
-      const int lb = 63 - __clzll((long long)pending);
-      const uint32_t ma = __shfl(farmask, la), mb = __shfl(farmask, lb);
-      const int ba = __ffs((int)ma) - 1, bb = 31 - __clz((int)mb);
-      const bool single = (la == lb) && (ba == bb);
-      if (lane == la) farmask &= ~(1u << ba);
-      if (lane == lb) farmask &= ~(1u << bb);
-      const bool upper = lane >= 32;
-      const bool act = !upper || !single;
-      const int src = upper ? lb : la, bit = upper ? bb : ba;
-      const uint32_t pr = __shfl(pair, src);
-      const int l = bit >> 2, ch = lane & 31;
-      const uint32_t s = (pr * (uint32_t)L + (uint32_t)l) * 4u + (uint32_t)(bit & 3);
-      const int H = s_H[l], W = s_W[l];
-      float ga = 0.f, gw = 0.f, gh = 0.f;
-      if (act) {
-        const uint32_t m = pr % (uint32_t)M, n = (pr / (uint32_t)M) / Lq;
-        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
-        const float a = aw[s];
-        const Corner4<float> g = corner_setup<float>(xy.x, xy.y, H, W);
-        const uint32_t rowf = (uint32_t)M * 32u;
-        const uint32_t base = ((n * (uint32_t)S + (uint32_t)s_lsi[l]) * (uint32_t)M + m) * 32u + (uint32_t)ch;
-        const float tg = ldval(grad_out, pr * 32u + (uint32_t)ch), tgv = tg * a;
-        // an in-level corner takes part even when its weight is exactly 0 (its value still
-        // enters d/d loc); out-of-level corners read as 0 and scatter nothing
-        const float v1 = g.ok1 ? ldval(value, base + (uint32_t)g.o1 * rowf) : 0.f;
-        const float v2 = g.ok2 ? ldval(value, base + (uint32_t)g.o2 * rowf) : 0.f;
-        const float v3 = g.ok3 ? ldval(value, base + (uint32_t)g.o3 * rowf) : 0.f;
-        const float v4 = g.ok4 ? ldval(value, base + (uint32_t)g.o4 * rowf) : 0.f;
-        if (g.ok1) atomicAdd(grad_value + base + (uint32_t)g.o1 * rowf, g.k1 * tgv);
-        if (g.ok2) atomicAdd(grad_value + base + (uint32_t)g.o2 * rowf, g.k2 * tgv);
-        if (g.ok3) atomicAdd(grad_value + base + (uint32_t)g.o3 * rowf, g.k3 * tgv);
-        if (g.ok4) atomicAdd(grad_value + base + (uint32_t)g.o4 * rowf, g.k4 * tgv);
-        ga = tg * (g.k1 * v1 + g.k2 * v2 + g.k3 * v3 + g.k4 * v4);
-        gw = tgv * (g.hh * (v2 - v1) + g.lh * (v4 - v3));
-        gh = tgv * (g.hw * (v3 - v1) + g.lw * (v4 - v2));
-      }
-      ga = group_sum<float, 32>(ga);
-      gw = group_sum<float, 32>(gw);
-      gh = group_sum<float, 32>(gh);
-      if (act && ch == 0) {
-        grad_aw[s] = ga;
-        *reinterpret_cast<float2 *>(grad_loc + 2u * s) = make_float2((float)W * gw, (float)H * gh);
-      }
-    }
-  }
-}
-
-}  // namespace tiled
-
-// =======================================================================================
-// Backward, fp32 arithmetic, D == 32, P <= 4, any Lq: *binned* destination-tiled backward.
-//
-// Same accumulation scheme as msda_bwd_tiled_kernel above (a workgroup owns the 256
-// grad_value rows of one (image, head, level, 16x16 tile) in registers; per-pixel LDS buckets
-// filled with integer LDS atomics; no float atomic anywhere), but the workgroup no longer
-// *searches* a candidate rectangle for the samples that land in its tile: a counting sort
-// hands every tile the list of its samples.  That removes most of the examination redundancy
-// (3.5 candidates per hit -> 1.3), the near/far split (any distribution of sampling locations
-// runs through the same kernels, no atomics) and the Lq == S restriction.
-//
-//   A list entry is one *quad* -- the (up to 4) points of one (image, query, head, level) --
-//   plus a mask of the points that have at least one in-level corner inside the tile; a quad
-//   is listed once in every tile its points touch (model-like locations: 1.35 tiles per quad,
-//   3.0 of 4 points live per entry).  Four threads examine one entry, one point each, exactly
-//   as the candidate kernel examined one query; everything after the examination is shared.
-//
-// Kernels, all on the caller's stream, all reading the level shapes on the device:
-//   msda_bwd_bin_zero_kernel    clears the per-tile counters,
-//   msda_bwd_bin_kernel<false>  counts entries per (image, level, tile, head) -- LDS histogram
-//                               per workgroup, one global atomic per touched key,
-//   msda_bwd_bin_scan_kernel    exclusive prefix sum -> list starts,
-//   msda_bwd_bin_kernel<true>   writes the entries to their lists, and the zero gradients of
-//                               gate-closed samples,
-//   msda_bwd_binned_kernel      the tile kernel.
-// Workspace (caller-provided), uint32 words: counters[key_cap + 1], starts[key_cap + 1],
-// descriptors[quads], entries[16 * quads]; key_cap = N*M*S >= number of lists (a level has at most H*W tiles), and
-// a quad touches at most 16 tiles (typically 1-2: the bound is address space, not traffic).
-// =======================================================================================
-namespace binned {
-
-#ifdef MSDA_PHASE_STAMPS
-using tiled::g_phase_cycles;
-#endif
-using tiled::sum2;
-using tiled::uni;
-using tiled::unif;
 
 constexpr int T = 16;
 constexpr int TP = T * T;
@@ -1544,7 +991,11 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
         s_hcount[par ^ 1] = 0u;
         s_max[par ^ 1] = 0u;
       }
+#ifdef MSDA_EXPERIMENT_ONE_ROUND   // timing experiment only (drops overflowed contributions)
+      const uint32_t rounds = 1u;
+#else
       const uint32_t rounds = (uint32_t)uni((int)s_max[par]) / (uint32_t)KB + 1u;   // 1 unless a bucket overflowed
+#endif
       MSDA_STAMP(3)
       for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t lo = r * (uint32_t)KB;
@@ -1852,21 +1303,6 @@ int backward_impl<double>(const char *who, const double *value, const int64_t *s
                                  static_cast<hipStream_t>(stream));
 }
 
-template <typename VT>
-int launch_backward_tiled(const char *who, const VT *value, const int64_t *shapes,
-                          const int64_t *lsi, const float *loc, const float *aw,
-                          const VT *grad_out, int N, int S, int M, int L, float *grad_value,
-                          float *grad_loc, float *grad_aw, hipStream_t st) {
-  const int cus = num_cus();
-  hipLaunchKernelGGL(tiled::msda_bwd_tiled_kernel<VT>, dim3(2 * cus), dim3(tiled::NT), 0, st,
-                     grad_out, value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc,
-                     grad_aw);
-  if (int rc = check_launch(who)) return rc;
-  hipLaunchKernelGGL(tiled::msda_bwd_far_kernel<VT>, dim3(8 * cus), dim3(256), 0, st, grad_out,
-                     value, shapes, lsi, loc, aw, N, S, M, L, grad_value, grad_loc, grad_aw);
-  return check_launch(who);
-}
-
 // ---- binned backward: shape test, workspace size, launches ----
 bool binned_shape(int N, int S, int M, int D, int L, int Lq, int P) {
   if (!(D == 32 && P <= binned::MAXP && L <= binned::MAXL && N > 0 && S > 0 && Lq > 0)) return false;
@@ -1927,13 +1363,11 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
   return check_launch(who);
 }
 
-// Which D == 32 backward: "binned" (default), "tiled" (round-1 candidate-rectangle kernels,
-// kept for A/B measurements), "generic" (atomics).
+// Which D == 32 backward: binned (default) or, with MSDA_BWD_IMPL=generic, the atomic kernel
+// (A/B measurements).
 int bwd_impl_choice() {
   const char *e = getenv("MSDA_BWD_IMPL");
-  if (e && strcmp(e, "generic") == 0) return 0;
-  if (e && strcmp(e, "tiled") == 0) return 1;
-  return 2;
+  return (e && strcmp(e, "generic") == 0) ? 0 : 2;
 }
 
 // Workspace from the device's stream-ordered pool when the caller brought none.
@@ -1959,9 +1393,6 @@ int backward_d32(const char *who, const VT *value, const int64_t *shapes, const 
                  const float *loc, const float *aw, const VT *grad_out, int N, int S, int M, int L,
                  int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw, void *workspace,
                  size_t workspace_bytes, bool own_workspace, hipStream_t st) {
-  if (bwd_impl_choice() == 1 && P == tiled::P && Lq == S)
-    return launch_backward_tiled<VT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L,
-                                     grad_value, grad_loc, grad_aw, st);
   if (!own_workspace)
     return launch_backward_binned<VT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
                                       grad_value, grad_loc, grad_aw, workspace, workspace_bytes, st);
@@ -2013,9 +1444,9 @@ extern "C" {
 // diagnostic build only: read (and clear) the per-phase cycle sums
 int msda_debug_phase_cycles(unsigned long long *out16) {
   if (hipDeviceSynchronize() != hipSuccess) return 1;
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(tiled::g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(binned::g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
   unsigned long long z[16] = {0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(tiled::g_phase_cycles), z, sizeof(z)) == hipSuccess ? 0 : 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(binned::g_phase_cycles), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
 #endif
 

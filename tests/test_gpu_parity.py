@@ -309,3 +309,126 @@ def test_bf16_variant_rejects_unsupported_shapes(msda):
     with pytest.raises(RuntimeError, match="dtype"):
         msda.ms_deform_attn_forward(v, shapes, lsi, torch.rand(1, 16, 2, 1, 4, 2).cuda().bfloat16(),
                                     torch.rand(1, 16, 2, 1, 4).cuda(), 128)
+
+
+# ---------------------------------------------------------------------------------------------
+# Binned backward (channels == 32): any number of queries / points <= 4 / odd level shapes take
+# the same kernels; the C ABI's workspace entry points.
+# ---------------------------------------------------------------------------------------------
+def _off_lattice(inp):
+    """Moves locations that fall within 1e-3 px of an integer pixel coordinate: there the
+    bilinear sample is not differentiable and fp32 rounding of loc * size - 0.5 (the kernels', and
+    the reference's) may pick the other one-sided derivative than the fp64 oracle."""
+    loc = inp["sampling_locations"]
+    for l, (h, w) in enumerate(inp["spatial_shapes"].tolist()):
+        for c, size in ((0, w), (1, h)):
+            pix = loc[..., l, :, c].double() * size - 0.5
+            near = (pix - pix.round()).abs() < 1e-3
+            loc[..., l, :, c] += near.float() * (3e-3 / size)
+    return inp
+
+
+@pytest.mark.parametrize("shapes,heads,points,num_query,dist", [
+    ([(40, 23), (17, 33), (5, 70)], 8, 4, 300, "uniform"),     # decoder-style: Lq != S, ragged tiles
+    ([(16, 16), (32, 32)], 3, 1, 77, "uniform"),               # one point, tiles exactly 16 x 16
+    ([(33, 17)], 2, 3, 1, "uniform"),                          # a single query
+    ([(64, 64), (32, 32), (16, 16)], 8, 4, None, "model"),     # fine level first (queue order)
+    ([(1, 200), (200, 1)], 4, 2, 50, "uniform"),               # strips: one tile per 16 pixels
+])
+def test_binned_backward_shapes_vs_oracle(msda, oracle, shapes, heads, points, num_query, dist):
+    from instaorder_amd import synthetic
+    kw = {} if num_query is None else {"num_query": num_query}
+    inp = synthetic.make_inputs(2, shapes, heads=heads, channels=32, points=points, dist=dist,
+                                seed=21, **kw)
+    if dist == "uniform":
+        inp["sampling_locations"] = inp["sampling_locations"] * 1.2 - 0.1     # some out of range
+    _oracle_check(msda, oracle, _off_lattice(inp), FWD_TOL_F32, GRAD_TOL_F32)
+
+
+def test_binned_backward_samples_on_tile_borders(msda, oracle):
+    """Locations on pixel centres and on tile borders (x = 15.5, 16, 16.5 px ...): footprints that
+    straddle two or four tiles, weights that are exactly 0 or 1.  Power-of-two level sizes keep
+    loc * size - 0.5 exact in fp32 and fp64 alike, so both sides floor the same way."""
+    from instaorder_amd import synthetic
+    shapes = [(64, 32), (32, 128)]
+    inp = synthetic.make_inputs(1, shapes, heads=2, channels=32, points=4, dist="uniform", seed=4,
+                                num_query=256)
+    loc = inp["sampling_locations"]
+    g = torch.Generator().manual_seed(9)
+    for l, (h, w) in enumerate(shapes):
+        # pixel coordinate k/2 for integer k  <=>  location (k/2 + 0.5) / size
+        kx = torch.randint(-2, 2 * w + 2, loc[..., l, :, 0].shape, generator=g).float()
+        ky = torch.randint(-2, 2 * h + 2, loc[..., l, :, 1].shape, generator=g).float()
+        loc[..., l, :, 0] = (kx / 2 + 0.5) / w
+        loc[..., l, :, 1] = (ky / 2 + 0.5) / h
+    _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
+
+
+def test_binned_backward_all_samples_on_one_pixel(msda, oracle):
+    """Every sample of every query lands on the same pixel: one list holds everything and its
+    buckets overflow many times over."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(1, [(20, 20)], heads=1, channels=32, points=4, dist="uniform",
+                                seed=2, num_query=700)
+    inp["sampling_locations"][...] = torch.tensor([0.53, 0.47])
+    _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
+
+
+def _abi():
+    import ctypes
+    from instaorder_amd import ext
+    return ext._load(), ctypes
+
+
+def test_c_abi_workspace_entry_points(msda):
+    """msda_backward_f32 (workspace from the stream-ordered pool), msda_backward_f32_ws (caller's
+    workspace) and the binding agree to rounding (list order, hence summation order, is not
+    fixed from run to run); a short workspace is refused."""
+    from instaorder_amd import synthetic
+    lib, ctypes = _abi()
+    inp = synthetic.make_inputs(2, synthetic.encoder_shapes(256), dist="model", seed=3, device="cuda")
+    v, ss, lsi = inp["value"], inp["spatial_shapes"], inp["level_start_index"]
+    loc, aw, go = inp["sampling_locations"], inp["attention_weights"], inp["grad_output"]
+    n, s, m, d = v.shape
+    nl, lq, p = ss.shape[0], loc.shape[1], loc.shape[4]
+    ref = msda.ms_deform_attn_backward(v, ss, lsi, loc, aw, go, 128)
+    need = int(lib.msda_backward_workspace_bytes(n, s, m, d, nl, lq, p))
+    assert need > 0
+    assert int(lib.msda_backward_workspace_bytes(n, s, m, 64, nl, lq, p)) == 0     # generic path
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(fn, *extra):
+        gv, gl, ga = torch.full_like(v, 7.0), torch.full_like(loc, 7.0), torch.full_like(aw, 7.0)
+        rc = fn(v.data_ptr(), ss.data_ptr(), lsi.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                go.data_ptr(), n, s, m, d, nl, lq, p, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+                *extra, stream)
+        return rc, gv, gl, ga
+
+    rc, gv, gl, ga = call(lib.msda_backward_f32)
+    assert rc == 0, lib.msda_last_error()
+    torch.cuda.synchronize()
+    for got, want in zip((gv, gl, ga), ref):
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    ws = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
+    rc, gv, gl, ga = call(lib.msda_backward_f32_ws, ws.data_ptr(), need)
+    assert rc == 0, lib.msda_last_error()
+    torch.cuda.synchronize()
+    for got, want in zip((gv, gl, ga), ref):
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    rc, *_ = call(lib.msda_backward_f32_ws, ws.data_ptr(), need - 1)
+    assert rc != 0 and b"workspace" in lib.msda_last_error()
+    rc, *_ = call(lib.msda_backward_f32_ws, None, 0)
+    assert rc != 0 and b"workspace" in lib.msda_last_error()
+
+
+def test_backward_run_to_run_agreement(msda):
+    """No float atomics on the D == 32 path, but the order of a tile's list (and with it the
+    order of the sums) is not fixed: two runs agree to rounding, nothing more is promised."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(2, synthetic.encoder_shapes(256), dist="uniform", seed=8, device="cuda")
+    args = (inp["value"], inp["spatial_shapes"], inp["level_start_index"], inp["sampling_locations"],
+            inp["attention_weights"], inp["grad_output"], 128)
+    a = msda.ms_deform_attn_backward(*args)
+    b = msda.ms_deform_attn_backward(*args)
+    for x, y in zip(a, b):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-6

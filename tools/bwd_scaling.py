@@ -1,4 +1,4 @@
-"""Per-image backward/forward time vs batch size (is the tiled backward memory-bound?)."""
+"""Per-image backward/forward time vs batch size (is the backward memory-bound?)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle shares of the tiled backward (needs tools/bin/libmsda_hip_stamps.so,
+"""Diagnostic: per-phase cycle shares of the backward tile kernel (needs tools/bin/libmsda_hip_stamps.so,
 built with -DMSDA_PHASE_STAMPS).  Shares only -- the stamped build is slower than the real one."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
