@@ -1,0 +1,88 @@
+// Micro-benchmark: how fast can a CU gather 128-B rows through the vector L1 (TA/TCP) on gfx950,
+// for the lane mappings the MSDA forward could use and for L1-resident vs L2-resident rows?
+// Build: hipcc -O3 --offload-arch=gfx950 -o tools/bin/mb_gather tools/microbench_gather.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+constexpr int NLOAD = 16;      // independent row loads in flight per lane group
+
+template <int LPR> struct Vec;
+template <> struct Vec<8> { typedef float4 type; };
+template <> struct Vec<16> { typedef float2 type; };
+template <> struct Vec<32> { typedef float type; };
+__device__ __forceinline__ float sum(float4 v) { return v.x + v.y + v.z + v.w; }
+__device__ __forceinline__ float sum(float2 v) { return v.x + v.y; }
+__device__ __forceinline__ float sum(float v) { return v; }
+
+// LPR lanes own one row per load (128 / LPR bytes per lane).
+// PATTERN 0: every lane group draws its own random row of the footprint.
+// PATTERN 1: the groups of a wave take consecutive rows starting at a random one (one contiguous
+//            64/LPR * 128-B span per wave-instruction).
+// PATTERN 2: pairs of neighbouring groups share one random row (half the distinct lines).
+template <int LPR, int PATTERN>
+__global__ __launch_bounds__(256) void gather(const char *__restrict__ base, uint32_t row_mask,
+                                              int iters, float *out) {
+  typedef typename Vec<LPR>::type V;
+  const uint32_t lane = threadIdx.x & 63u, grp = lane / LPR, sub = lane % LPR;
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  uint32_t h = PATTERN == 0 ? (wave * (64u / LPR) + grp) * 2654435761u + 12345u
+             : PATTERN == 1 ? wave * 2654435761u + 12345u
+                            : (wave * (64u / LPR) + (grp >> 1)) * 2654435761u + 12345u;
+  float acc = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    V v[NLOAD];
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+      h = h * 1664525u + 1013904223u;
+      uint32_t row = (h >> 9);
+      if (PATTERN == 1) row += grp;
+      row &= row_mask;
+      v[j] = *reinterpret_cast<const V *>(base + (size_t)row * 128u + sub * (128u / LPR));
+    }
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) acc += sum(v[j]);
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int LPR, int PATTERN>
+void run(const char *name, const char *d, float *o, uint32_t rows, double ghz, int cus) {
+  const int blocks = cus * 8, iters = 256;   // 8 blocks of 4 waves per CU (all resident at 4 waves/SIMD... 2 rounds)
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL((gather<LPR, PATTERN>), dim3(blocks), dim3(256), 0, 0, d, rows - 1, iters, o);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  hipLaunchKernelGGL((gather<LPR, PATTERN>), dim3(blocks), dim3(256), 0, 0, d, rows - 1, iters, o);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+  const double row_loads = (double)blocks * 4 * (64 / LPR) * iters * NLOAD;     // row touches
+  const double per_cu = row_loads / cus;
+  printf("%-58s rows=%7u (%6.0f KiB) %7.3f ms  %5.2f clk/row/CU  %6.2f TB/s\n", name, rows, rows * 128.0 / 1024, ms,
+         ms * 1e-3 * ghz * 1e9 / per_cu, row_loads * 128 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+  hipDeviceProp_t p;
+  CHECK(hipGetDeviceProperties(&p, 0));
+  const double ghz = p.clockRate / 1e6;
+  const int cus = p.multiProcessorCount;
+  printf("%s: %d CUs, %.2f GHz\n", p.name, cus, ghz);
+  const size_t bytes = (size_t)1 << 30;
+  char *d; float *o;
+  CHECK(hipMalloc(&d, bytes)); CHECK(hipMalloc(&o, 4));
+  CHECK(hipMemset(d, 0, bytes));
+  const uint32_t sizes[] = {64, 128, 1024, 16384, 131072, 4194304};   // 8 KiB, 16 KiB, 128 KiB, 2 MiB, 16 MiB, 512 MiB
+  for (uint32_t rows : sizes) {
+    run<8, 0>("8 lanes x dwordx4, random row per group", d, o, rows, ghz, cus);
+    run<16, 0>("16 lanes x dwordx2, random row per group", d, o, rows, ghz, cus);
+    run<32, 0>("32 lanes x dword, random row per group", d, o, rows, ghz, cus);
+    run<8, 1>("8 lanes x dwordx4, 8 consecutive rows per wave", d, o, rows, ghz, cus);
+    run<8, 2>("8 lanes x dwordx4, neighbouring groups share a row", d, o, rows, ghz, cus);
+  }
+  return 0;
+}
