@@ -223,6 +223,141 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // =======================================================================================
+// Forward, fp32 arithmetic, D == 32, L*P <= 32: the kernel every InstaFormer shape runs.
+// Replaces ms_deformable_im2col_gpu_kernel<float> (ms_deform_im2col_cuda.cuh:242-304).
+//
+// What the measurements behind it say (tools/microbench_gather.hip, profiles/r01):
+//   * the vector L1 path charges per lane-group row touch, ~2 clk per 8 rows of 16 B/lane
+//     wave-instruction, whether the rows hit in L1 or in L2 and whether lane groups share
+//     a line; a dwordx2 instruction costs as much as a dwordx4 one.  So every lane always
+//     moves 16 B: an fp32 row (128 B) takes 8 lanes, a bf16 row (64 B) takes 4.
+//   * the kernel above recomputes a sample's geometry in all lanes of its pair and waits for a
+//     round trip to HBM for the locations of every level.
+// A wave owns GP = 64/LPG CONSECUTIVE QUERIES OF ONE HEAD (not the heads of one query):
+// neighbouring queries sample neighbouring, often the same, pixel rows, and in this mapping
+// those repeats sit inside one wave-instruction instead of arriving from other waves while the
+// line is still being filled (TCP->L2 requests -43 %).
+//   phase 1: lane i takes samples i, i + 64, ... of the wave's GP*L*P samples (ONE round trip
+//            to HBM for locations and weights), runs corner_setup once per sample and leaves
+//            (4 corner weights * attn, 4 row byte offsets) in a wave-private LDS region;
+//   phase 2: the LPG lanes of a query walk its samples NS at a time: two broadcast
+//            ds_read_b128 per sample, then 4 row loads of 16 B and 4*CH FMAs per lane.
+// Per-query LDS regions are padded by 16 B so the broadcast addresses of a ds_read_b128 fall in
+// different banks for every L*P.  Dynamic LDS: 4 waves * 2 * GP * (L*P + 1) * 16 bytes.
+// =======================================================================================
+template <typename VT> struct FwdLanes;
+template <> struct FwdLanes<float> { static constexpr int LPG = 8, CH = 4; };
+template <> struct FwdLanes<bf16_t> { static constexpr int LPG = 4, CH = 8; };
+
+__device__ __forceinline__ uint4 ld_raw16(const void *__restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void fma_piece(float (&acc)[4], float k, uint4 r, const float *) {
+  acc[0] = fmaf(k, __uint_as_float(r.x), acc[0]);
+  acc[1] = fmaf(k, __uint_as_float(r.y), acc[1]);
+  acc[2] = fmaf(k, __uint_as_float(r.z), acc[2]);
+  acc[3] = fmaf(k, __uint_as_float(r.w), acc[3]);
+}
+__device__ __forceinline__ void fma_piece(float (&acc)[8], float k, uint4 r, const bf16_t *) {
+  acc[0] = fmaf(k, __uint_as_float(r.x << 16), acc[0]);
+  acc[1] = fmaf(k, __uint_as_float(r.x & 0xffff0000u), acc[1]);
+  acc[2] = fmaf(k, __uint_as_float(r.y << 16), acc[2]);
+  acc[3] = fmaf(k, __uint_as_float(r.y & 0xffff0000u), acc[3]);
+  acc[4] = fmaf(k, __uint_as_float(r.z << 16), acc[4]);
+  acc[5] = fmaf(k, __uint_as_float(r.z & 0xffff0000u), acc[5]);
+  acc[6] = fmaf(k, __uint_as_float(r.w << 16), acc[6]);
+  acc[7] = fmaf(k, __uint_as_float(r.w & 0xffff0000u), acc[7]);
+}
+__device__ __forceinline__ uint4 pack_piece(const float (&a)[4], const float *) {
+  return make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
+}
+__device__ __forceinline__ uint4 pack_piece(const float (&a)[8], const bf16_t *) {
+  return make_uint4(f32_to_bf16(a[0]) | (f32_to_bf16(a[1]) << 16), f32_to_bf16(a[2]) | (f32_to_bf16(a[3]) << 16),
+                    f32_to_bf16(a[4]) | (f32_to_bf16(a[5]) << 16), f32_to_bf16(a[6]) | (f32_to_bf16(a[7]) << 16));
+}
+
+// NS samples of one query: all 4*NS row pieces are requested before the first is used.
+template <typename VT, int NS>
+__device__ __forceinline__ void fwd_rows_d32(const VT *__restrict__ value, uint32_t vbyte,
+                                             const float4 *__restrict__ sk, const uint4 *__restrict__ so,
+                                             float (&acc)[FwdLanes<VT>::CH]) {
+  float4 k[NS];
+  uint4 v[NS][4];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    k[i] = sk[i];
+    const uint4 o = so[i];
+    v[i][0] = ld_raw16(value, vbyte + o.x);
+    v[i][1] = ld_raw16(value, vbyte + o.y);
+    v[i][2] = ld_raw16(value, vbyte + o.z);
+    v[i][3] = ld_raw16(value, vbyte + o.w);
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    fma_piece(acc, k[i].x, v[i][0], value);
+    fma_piece(acc, k[i].y, v[i][1], value);
+    fma_piece(acc, k[i].z, v[i][2], value);
+    fma_piece(acc, k[i].w, v[i][3], value);
+  }
+}
+
+constexpr size_t FWD_QH_MAX_LDS = 48 * 1024;   // dynamic LDS per block the launcher accepts: L*P <= 47 (fp32), 23 (bf16)
+
+template <typename VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_fwd_d32_qh_kernel(
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const float *__restrict__ loc,
+    const float *__restrict__ aw, int S, int M, int L, int Lq, int P, uint32_t nq,
+    uint32_t nunits, uint32_t nblocks, VT *__restrict__ out) {
+  constexpr uint32_t LPG = FwdLanes<VT>::LPG, GP = 64u / LPG, CH = FwdLanes<VT>::CH;
+  extern __shared__ float4 s_dyn[];
+  const uint32_t LP = (uint32_t)(L * P);
+  const uint32_t pstride = LP + 1u;                                  // float4 units per query, padded
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  float4 *sk = s_dyn + wave * 2u * GP * pstride;                     // [GP][pstride] corner weights * attn
+  uint4 *so = reinterpret_cast<uint4 *>(sk + GP * pstride);          // [GP][pstride] row byte offsets
+  const uint32_t unit = xcd_remap(blockIdx.x, nblocks) * 4u + wave;  // (run of GP queries, head)
+  if (unit >= nunits) return;
+  const uint32_t run = unit / (uint32_t)M, m = unit - run * (uint32_t)M;
+  const uint32_t q0 = run * GP;                                      // first n*Lq + q of the wave
+  const uint32_t row_bytes = (uint32_t)M * 32u * (uint32_t)sizeof(VT);
+  {
+    const uint32_t nsamp = min(GP, nq - q0) * LP;
+    for (uint32_t i = lane; i < nsamp; i += 64u) {
+      const uint32_t g = i / LP, j = i - g * LP, l = j / (uint32_t)P;
+      const uint32_t s = ((q0 + g) * (uint32_t)M + m) * LP + j;
+      const float2 xy = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(loc) + s * 8u);
+      const float a = aw[s];
+      const int H = (int)shapes[2u * l], W = (int)shapes[2u * l + 1u];
+      const uint32_t lrow = (uint32_t)lsi[l];
+      const Corner4<float> c = corner_setup<float>(xy.x, xy.y, H, W);
+      sk[g * pstride + j] = make_float4(c.k1 * a, c.k2 * a, c.k3 * a, c.k4 * a);
+      so[g * pstride + j] = make_uint4((lrow + (uint32_t)c.o1) * row_bytes, (lrow + (uint32_t)c.o2) * row_bytes,
+                                       (lrow + (uint32_t)c.o3) * row_bytes, (lrow + (uint32_t)c.o4) * row_bytes);
+    }
+  }
+  // the region is private to the wave: order its LDS writes before the reads below, no s_barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t g = lane / LPG, sub = lane % LPG;
+  const uint32_t q = q0 + g;
+  if (q >= nq) return;
+  const uint32_t n = q / (uint32_t)Lq;
+  const uint32_t vbyte = n * (uint32_t)S * row_bytes + m * 32u * (uint32_t)sizeof(VT) + sub * 16u;
+  float acc[CH];
+#pragma unroll
+  for (uint32_t c = 0; c < CH; ++c) acc[c] = 0.f;
+  const float4 *pk = sk + g * pstride;
+  const uint4 *po = so + g * pstride;
+  uint32_t j = 0;
+  for (; j + 4u <= LP; j += 4u) fwd_rows_d32<VT, 4>(value, vbyte, pk + j, po + j, acc);
+  for (; j < LP; ++j) fwd_rows_d32<VT, 1>(value, vbyte, pk + j, po + j, acc);
+  *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(out) + (q * (uint32_t)M + m) * 32u * (uint32_t)sizeof(VT) + sub * 16u) =
+      pack_piece(acc, value);
+}
+
+// =======================================================================================
 // Forward, any D, fp32 / fp64.  G lanes (a power of two <= 64) own one pair and stride
 // over its channels.  Same reference kernel as above; this is the path ops/test.py's
 // D in {30, 64, 71, 1025, 2048, 3096} and every fp64 call take.  64-bit indexing.
@@ -1230,10 +1365,28 @@ int forward_impl<double>(const double *value, const int64_t *shapes, const int64
                                  static_cast<hipStream_t>(stream));
 }
 
+// Which D == 32 forward: queries-by-head (default) or, with MSDA_FWD_IMPL=plain, the
+// heads-of-a-query kernel (A/B measurements; also the path of L*P > 32 and unaligned tensors).
+int fwd_impl_choice() {
+  const char *e = getenv("MSDA_FWD_IMPL");
+  return (e && strcmp(e, "plain") == 0) ? 0 : 1;
+}
+
 template <typename VT>
 void launch_forward_d32(const VT *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                         const float *aw, int S, int M, int L, int Lq, int P, size_t npairs, VT *out,
                         hipStream_t st) {
+  static const int impl = fwd_impl_choice();
+  constexpr uint32_t GP = 64u / FwdLanes<VT>::LPG;
+  const size_t lds = (size_t)4 * 2 * GP * (size_t)(L * P + 1) * 16;
+  if (impl != 0 && lds <= FWD_QH_MAX_LDS && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0 && aligned16(value) &&
+      aligned16(out)) {
+    const uint32_t nq = (uint32_t)(npairs / (size_t)M), nunits = ((nq + GP - 1u) / GP) * (uint32_t)M;
+    const uint32_t nblk = (nunits + 3u) / 4u;
+    hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT>), dim3(nblk), dim3(256), lds, st, value, shapes, lsi,
+                       loc, aw, S, M, L, Lq, P, nq, nunits, nblk, out);
+    return;
+  }
   const uint32_t nblk = (uint32_t)((npairs + 31) / 32);
   if (P == 4 && aligned16(loc) && aligned16(aw))
     hipLaunchKernelGGL((msda_fwd_d32_kernel<VT, true>), dim3(nblk), dim3(256), 0, st, value, shapes,

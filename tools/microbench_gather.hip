@@ -66,6 +66,44 @@ void run(const char *name, const char *d, float *o, uint32_t rows, double ghz, i
          ms * 1e-3 * ghz * 1e9 / per_cu, row_loads * 128 / (ms * 1e-3) / 1e12);
 }
 
+template <int NL, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gather_depth(
+    const char *__restrict__ base, uint32_t row_mask, int iters, float *out) {
+  const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, sub = lane & 7u;
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  uint32_t h = (wave * 8u + grp) * 2654435761u + 12345u;
+  float acc = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    float4 v[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      h = h * 1664525u + 1013904223u;
+      const uint32_t row = (h >> 9) & row_mask;
+      v[j] = *reinterpret_cast<const float4 *>(base + (size_t)row * 128u + sub * 16u);
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) acc += sum(v[j]);
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int NL, int WPE>
+void depth(const char *d, float *o, uint32_t rows, double ghz, int cus) {
+  const int blocks = cus * WPE * 4, iters = 4096 / NL;   // WPE waves per SIMD resident, several rounds
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL((gather_depth<NL, WPE>), dim3(blocks), dim3(256), 0, 0, d, rows - 1, iters, o);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  hipLaunchKernelGGL((gather_depth<NL, WPE>), dim3(blocks), dim3(256), 0, 0, d, rows - 1, iters, o);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+  const double row_loads = (double)blocks * 4 * 8 * iters * NL;
+  printf("depth: %2d loads/wave x %d waves/SIMD (%4d wave-loads per CU) rows=%6u  %5.2f clk/row/CU  %6.2f TB/s\n", NL, WPE,
+         NL * WPE * 4, rows, ms * 1e-3 * ghz * 1e9 / (row_loads / cus), row_loads * 128 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
   hipDeviceProp_t p;
   CHECK(hipGetDeviceProperties(&p, 0));
@@ -76,13 +114,20 @@ int main() {
   char *d; float *o;
   CHECK(hipMalloc(&d, bytes)); CHECK(hipMalloc(&o, 4));
   CHECK(hipMemset(d, 0, bytes));
-  const uint32_t sizes[] = {64, 128, 1024, 16384, 131072, 4194304};   // 8 KiB, 16 KiB, 128 KiB, 2 MiB, 16 MiB, 512 MiB
+  const uint32_t sizes[] = {128, 16384};   // 8 KiB, 16 KiB, 128 KiB, 2 MiB, 16 MiB, 512 MiB
   for (uint32_t rows : sizes) {
     run<8, 0>("8 lanes x dwordx4, random row per group", d, o, rows, ghz, cus);
     run<16, 0>("16 lanes x dwordx2, random row per group", d, o, rows, ghz, cus);
     run<32, 0>("32 lanes x dword, random row per group", d, o, rows, ghz, cus);
     run<8, 1>("8 lanes x dwordx4, 8 consecutive rows per wave", d, o, rows, ghz, cus);
     run<8, 2>("8 lanes x dwordx4, neighbouring groups share a row", d, o, rows, ghz, cus);
+  }
+  // in-flight depth: waves per SIMD x loads per wave, 8 lanes x dwordx4, random rows
+  for (uint32_t rows : {128u, 16384u}) {
+    depth<8, 1>(d, o, rows, ghz, cus); depth<16, 1>(d, o, rows, ghz, cus); depth<32, 1>(d, o, rows, ghz, cus);
+    depth<8, 2>(d, o, rows, ghz, cus); depth<16, 2>(d, o, rows, ghz, cus); depth<32, 2>(d, o, rows, ghz, cus);
+    depth<8, 4>(d, o, rows, ghz, cus); depth<16, 4>(d, o, rows, ghz, cus); depth<32, 4>(d, o, rows, ghz, cus);
+    depth<4, 8>(d, o, rows, ghz, cus); depth<8, 8>(d, o, rows, ghz, cus); depth<16, 8>(d, o, rows, ghz, cus);
   }
   return 0;
 }
