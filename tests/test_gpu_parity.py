@@ -90,7 +90,7 @@ def test_encoder_shape_vs_oracle_f32(msda, oracle, dist):
 
 
 @pytest.mark.parametrize("channels,heads,points,levels", [
-    (32, 8, 3, 2), (32, 5, 4, 4), (16, 4, 4, 3), (64, 2, 2, 3), (71, 2, 2, 2), (30, 3, 5, 1),
+    (32, 8, 3, 2), (32, 5, 4, 4), (32, 2, 13, 4), (16, 4, 4, 3), (64, 2, 2, 3), (71, 2, 2, 2), (30, 3, 5, 1),
     (1025, 1, 2, 2), (2048, 1, 1, 2), (3096, 1, 2, 1), (1, 2, 2, 2)])
 def test_generic_shapes_vs_oracle(msda, oracle, channels, heads, points, levels):
     """Odd head sizes / point counts, incl. every D the reference's ops/test.py:88 lists."""
@@ -297,6 +297,53 @@ def test_bf16_variant_vs_oracle(msda, oracle, dist, image, batch):
     assert rel_err(gv.cpu().numpy(), o_gv) < GRAD_TOL_F32
     assert rel_err(gl.cpu().numpy(), o_gl) < GRAD_TOL_F32
     assert rel_err(ga.cpu().numpy(), o_ga) < GRAD_TOL_F32
+
+
+def test_bf16_variant_ragged_shapes_vs_oracle(msda, oracle):
+    """bf16 forward on a query count that is no multiple of the 16 queries a wave owns, 3 heads,
+    3 points, odd level shapes, some locations out of range."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(3, [(7, 9), (5, 3)], heads=3, channels=32, points=3, dist="uniform",
+                                seed=8, num_query=37)
+    inp["sampling_locations"] = inp["sampling_locations"] * 1.3 - 0.15
+    v16, go16 = inp["value"].to(torch.bfloat16), inp["grad_output"].to(torch.bfloat16)
+    dev = {k: t.cuda() for k, t in inp.items()}
+    out = msda.ms_deform_attn_forward(v16.cuda(), dev["spatial_shapes"], dev["level_start_index"],
+                                      dev["sampling_locations"], dev["attention_weights"], 128)
+    gv, gl, ga = msda.ms_deform_attn_backward(v16.cuda(), dev["spatial_shapes"],
+                                              dev["level_start_index"], dev["sampling_locations"],
+                                              dev["attention_weights"], go16.cuda(), 128)
+    n = lambda t: t.double().numpy() if t.is_floating_point() else t.numpy()
+    args = (n(v16.float()), n(inp["spatial_shapes"]), n(inp["level_start_index"]),
+            n(inp["sampling_locations"]), n(inp["attention_weights"]))
+    o_out = oracle.forward(*args)
+    o_gv, o_gl, o_ga = oracle.backward(*args, n(go16.float()))
+    assert rel_err(out.float().cpu().numpy(), o_out) < BF16_TOL
+    assert rel_err(gv.cpu().numpy(), o_gv) < GRAD_TOL_F32
+    assert rel_err(gl.cpu().numpy(), o_gl) < GRAD_TOL_F32
+    assert rel_err(ga.cpu().numpy(), o_ga) < GRAD_TOL_F32
+
+
+def test_forward_kernel_variants_agree(msda, tmp_path):
+    """The queries-by-head forward (default) and the heads-of-a-query kernel (the path of large
+    L*P; MSDA_FWD_IMPL=plain is read once per process) compute the same sums in the same order."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import torch, numpy; "
+            "import MultiScaleDeformableAttention as M; from instaorder_amd import synthetic; "
+            "i = synthetic.make_inputs(2, synthetic.encoder_shapes(256), seed=3, device='cuda'); "
+            "o = M.ms_deform_attn_forward(i['value'], i['spatial_shapes'], i['level_start_index'], "
+            "i['sampling_locations'], i['attention_weights'], 128); "
+            "numpy.save(sys.argv[1], o.cpu().numpy())" % root)
+    outs = []
+    for impl in ("plain", "default"):
+        path = str(tmp_path / (impl + ".npy"))
+        subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MSDA_FWD_IMPL=impl),
+                       timeout=110, check=True)
+        outs.append(np.load(path))
+    assert rel_err(outs[1], outs[0]) < 1e-6
 
 
 def test_bf16_variant_rejects_unsupported_shapes(msda):
