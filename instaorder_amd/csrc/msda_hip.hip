@@ -551,6 +551,9 @@ __device__ __forceinline__ float sum2(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 constexpr int T = 16;
 constexpr int TP = T * T;
 constexpr int VT = T + 1;
@@ -769,12 +772,11 @@ __global__ __launch_bounds__(BIN_NT) void msda_bwd_bin_kernel(
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (pt[j].in) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const int ty = tymin + (c >> 1), tx = txmin + (c & 1);
-                if ((ty == pt[j].tya || ty == pt[j].tyb) && (tx == pt[j].txa || tx == pt[j].txb))
-                  d |= 1u << (15 + 4 * c + j);
-              }
+              // rows / columns of the 2 x 2 tile block the point touches (bit 0: first, bit 1: second)
+              const uint32_t rm = (1u << (pt[j].tya - tymin)) | (1u << (pt[j].tyb - tymin));
+              const uint32_t cm = (1u << (pt[j].txa - txmin)) | (1u << (pt[j].txb - txmin));
+              const uint32_t c2 = (cm & 1u) | ((cm & 2u) << 3);                          // column bit x -> bit 4 * x
+              d |= (((rm & 1u) ? c2 : 0u) | ((rm & 2u) ? c2 << 8 : 0u)) << (15 + j);     // tile c = 2 * row + column -> bit 4 * c
             }
           for_each_fast(d, m, l, bump);
         } else {
@@ -1214,24 +1216,28 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
           const int rb = by * VT + bx;
           const int ra = (ok & 1u) ? rb : ZROW, rbb = (ok & 2u) ? rb + 1 : ZROW;
           const int rc = (ok & 4u) ? rb + VT : ZROW, rd = (ok & 8u) ? rb + VT + 1 : ZROW;
-          float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
+          // the four dot products as packed pairs (v_pk_fma_f32 on the register pairs the
+          // ds_read_b128 results already sit in)
+          v2f p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f}, p4 = {0.f, 0.f};
+          const char *gob = reinterpret_cast<const char *>(s_go) + hslot * 128 + half * 64;
+          const char *vtb = reinterpret_cast<const char *>(s_vt) + half * 64;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int c = half * 4 + ((k + (int)h) & 3);
-            const float4 g4 = s_go[hslot * 8 + c];
-            const float4 v1 = s_vt[ra * 8 + c];
-            const float4 v2 = s_vt[rbb * 8 + c];
-            const float4 v3 = s_vt[rc * 8 + c];
-            const float4 v4 = s_vt[rd * 8 + c];
-            d1 += g4.x * v1.x + g4.y * v1.y + g4.z * v1.z + g4.w * v1.w;
-            d2 += g4.x * v2.x + g4.y * v2.y + g4.z * v2.z + g4.w * v2.w;
-            d3 += g4.x * v3.x + g4.y * v3.y + g4.z * v3.z + g4.w * v3.w;
-            d4 += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+            const int cb = ((k + (int)h) & 3) * 16;
+            const v4f g4 = *reinterpret_cast<const v4f *>(gob + cb);
+            const v4f v1 = *reinterpret_cast<const v4f *>(vtb + ra * 128 + cb);
+            const v4f v2 = *reinterpret_cast<const v4f *>(vtb + rbb * 128 + cb);
+            const v4f v3 = *reinterpret_cast<const v4f *>(vtb + rc * 128 + cb);
+            const v4f v4 = *reinterpret_cast<const v4f *>(vtb + rd * 128 + cb);
+            p1 = __builtin_elementwise_fma(g4.zw, v1.zw, __builtin_elementwise_fma(g4.xy, v1.xy, p1));
+            p2 = __builtin_elementwise_fma(g4.zw, v2.zw, __builtin_elementwise_fma(g4.xy, v2.xy, p2));
+            p3 = __builtin_elementwise_fma(g4.zw, v3.zw, __builtin_elementwise_fma(g4.xy, v3.xy, p3));
+            p4 = __builtin_elementwise_fma(g4.zw, v4.zw, __builtin_elementwise_fma(g4.xy, v4.xy, p4));
           }
-          d1 = sum2(d1);
-          d2 = sum2(d2);
-          d3 = sum2(d3);
-          d4 = sum2(d4);
+          const float d1 = sum2(p1.x + p1.y);
+          const float d2 = sum2(p2.x + p2.y);
+          const float d3 = sum2(p3.x + p3.y);
+          const float d4 = sum2(p4.x + p4.y);
           if (half == 0) {
             const float lh = hr.x, lw = hr.y, a = hr.z, hh = 1.f - lh, hw = 1.f - lw;
             const uint32_t s = ((s_q[hslot] * (uint32_t)M + m) * (uint32_t)L + (uint32_t)l) * (uint32_t)P + (et & 3u);
