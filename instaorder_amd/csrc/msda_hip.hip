@@ -1107,23 +1107,40 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
         // The item's value tile (zeros outside the level).  fp32 rows go global -> LDS directly
         // (one 1-KiB wave-instruction per 64 consecutive pieces, no registers, all five in
         // flight at once); the barrier below waits for them.
+        if constexpr (sizeof(ST) == 4) {
 #pragma unroll 1
-        for (int j = 0; j < 5; ++j) {
-          const int t = tid + j * NT, row = t >> 3, sub = t & 7;
-          if (t < (ZROW + 1) * 8) {
-            const int y = y0 + row / VT, x = x0 + row % VT;
-            const bool inl = row < ZROW && y < H && x < W;
-            const uint32_t off = ((cur.lrow + (uint32_t)(y * W + x)) * (uint32_t)M + m) * 128u + (uint32_t)sub * 16u;
-            if constexpr (sizeof(ST) == 4) {
+          for (int j = 0; j < 5; ++j) {
+            const int t = tid + j * NT, row = t >> 3, sub = t & 7;
+            if (t < (ZROW + 1) * 8) {
+              const int y = y0 + row / VT, x = x0 + row % VT;
+              const bool inl = row < ZROW && y < H && x < W;
+              const uint32_t off = ((cur.lrow + (uint32_t)(y * W + x)) * (uint32_t)M + m) * 128u + (uint32_t)sub * 16u;
               if (inl)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(value) + off),
                     (__attribute__((address_space(3))) void *)(&s_vt[t - (tid & 63)]), 16, 0, 0);   // wave base: lane i lands 16*i further
               else
                 s_vt[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-              s_vt[t] = inl ? ldrow4(value, off) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+          }
+        } else {
+          // bf16 rows are widened on the way: request all five pieces, then convert and store
+          uint2 raw[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int t = tid + j * NT, row = t >> 3, sub = t & 7;
+            const int y = y0 + row / VT, x = x0 + row % VT;
+            const bool inl = t < (ZROW + 1) * 8 && row < ZROW && y < H && x < W;
+            const uint32_t off = ((cur.lrow + (uint32_t)(y * W + x)) * (uint32_t)M + m) * 64u + (uint32_t)sub * 8u;
+            raw[j] = make_uint2(0u, 0u);
+            if (inl) raw[j] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(value) + off);
+          }
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int t = tid + j * NT;
+            if (t < (ZROW + 1) * 8)
+              s_vt[t] = make_float4(bf16_to_f32(raw[j].x & 0xffffu), bf16_to_f32(raw[j].x >> 16),
+                                    bf16_to_f32(raw[j].y & 0xffffu), bf16_to_f32(raw[j].y >> 16));
           }
         }
       }
