@@ -135,6 +135,38 @@ int msda_backward_bf16_ws(const uint16_t *value, const int64_t *spatial_shapes,
                           float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
                           size_t workspace_bytes, void *stream);
 
+/*
+ * Fused boundary (opt-in, fp32): the op together with its two
+ * elementwise neighbours in the caller, ops/modules/ms_deform_attn.py:102-109 --
+ *   attn_weight  = softmax(attn_logits over num_levels * num_point)                  (:103-104)
+ *   sampling_loc = reference_points[n,q,None,l,None,:] + sampling_offsets / (W_l, H_l) (:106-109)
+ * so the caller passes the raw outputs of its two linears, reference_points [N,Lq,L,2],
+ * sampling_offsets [N,Lq,M,L,P,2], attn_logits [N,Lq,M,L*P], and gets gradients with respect to
+ * those.  No counterpart in the reference's extension (it takes sampling_loc / attn_weight,
+ * src/ms_deform_attn.h:25-32); the drop-in entry points above are unchanged.
+ * Forward: channels == 32 and num_levels * num_point <= 16, else MSDA_ERR_INVALID_ARGUMENT (fall
+ * back to the unfused entry points).  Backward: any shape msda_backward_f32 takes; the workspace
+ * (256-byte aligned, msda_fused_backward_workspace_bytes(...) bytes) holds the recomputed
+ * locations and weights plus the sort-by-tile lists.  No gradient for reference_points is
+ * returned (it is sum over heads and points of grad_sampling_offsets * (W_l, H_l)).
+ */
+int msda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
+                           const int64_t *level_start_index, const float *reference_points,
+                           const float *sampling_offsets, const float *attn_logits, int batch,
+                           int spatial_size, int num_heads, int channels, int num_levels,
+                           int num_query, int num_point, float *output, void *stream);
+
+size_t msda_fused_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                           int num_levels, int num_query, int num_point);
+
+int msda_fused_backward_f32(const float *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const float *reference_points,
+                            const float *sampling_offsets, const float *attn_logits,
+                            const float *grad_output, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point,
+                            float *grad_value, float *grad_sampling_offsets, float *grad_attn_logits,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,25 +303,74 @@ __device__ __forceinline__ void fwd_rows_d32(const VT *__restrict__ value, uint3
 
 constexpr size_t FWD_QH_MAX_LDS = 48 * 1024;   // dynamic LDS per block the launcher accepts: L*P <= 47 (fp32), 23 (bf16)
 
-template <typename VT>
+// FUSED (row f3 of SURVEY section 8, an opt-in second boundary): `loc` holds the raw sampling
+// OFFSETS and `aw` the attention LOGITS of the caller (ops/modules/ms_deform_attn.py:102-109);
+// phase 1 forms loc = reference_point + offset / (W_l, H_l) and the softmax over the L*P logits
+// of a (query, head) itself (logits through the wave's LDS region), so the caller's softmax and
+// location arithmetic -- one write and one read of both tensors -- disappear.  L*P <= 16.
+constexpr int FWD_FUSED_MAX_LP = 16;
+
+template <typename VT, bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_fwd_d32_qh_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
-    const float *__restrict__ aw, int S, int M, int L, int Lq, int P, uint32_t nq,
-    uint32_t nunits, uint32_t nblocks, VT *__restrict__ out) {
+    const float *__restrict__ aw, const float *__restrict__ refp, int S, int M, int L, int Lq, int P,
+    uint32_t nq, uint32_t nunits, uint32_t nblocks, VT *__restrict__ out) {
   constexpr uint32_t LPG = FwdLanes<VT>::LPG, GP = 64u / LPG, CH = FwdLanes<VT>::CH;
   extern __shared__ float4 s_dyn[];
   const uint32_t LP = (uint32_t)(L * P);
   const uint32_t pstride = LP + 1u;                                  // float4 units per query, padded
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  float4 *sk = s_dyn + wave * 2u * GP * pstride;                     // [GP][pstride] corner weights * attn
+  const uint32_t wave_f4 = 2u * GP * pstride + (FUSED ? (GP * LP + 3u) / 4u : 0u);   // float4 units per wave
+  float4 *sk = s_dyn + wave * wave_f4;                               // [GP][pstride] corner weights * attn
   uint4 *so = reinterpret_cast<uint4 *>(sk + GP * pstride);          // [GP][pstride] row byte offsets
   const uint32_t unit = xcd_remap(blockIdx.x, nblocks) * 4u + wave;  // (run of GP queries, head)
   if (unit >= nunits) return;
   const uint32_t run = unit / (uint32_t)M, m = unit - run * (uint32_t)M;
   const uint32_t q0 = run * GP;                                      // first n*Lq + q of the wave
   const uint32_t row_bytes = (uint32_t)M * 32u * (uint32_t)sizeof(VT);
-  {
+  if constexpr (FUSED) {
+    constexpr int FR = (int)(GP * FWD_FUSED_MAX_LP / 64u);            // sample rounds per lane
+    float *lg = reinterpret_cast<float *>(so + GP * pstride);       // [GP * LP] logits of the wave
+    const uint32_t nsamp = min(GP, nq - q0) * LP;
+    float2 offv[FR];
+#pragma unroll
+    for (int r = 0; r < FR; ++r) {
+      const uint32_t i = lane + 64u * (uint32_t)r;
+      offv[r] = make_float2(0.f, 0.f);
+      if (i < nsamp) {
+        const uint32_t g = i / LP, j = i - g * LP;
+        const uint32_t s = ((q0 + g) * (uint32_t)M + m) * LP + j;
+        offv[r] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(loc) + s * 8u);
+        lg[i] = aw[s];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < FR; ++r) {
+      const uint32_t i = lane + 64u * (uint32_t)r;
+      if (i >= nsamp) continue;
+      const uint32_t g = i / LP, j = i - g * LP, l = j / (uint32_t)P;
+      const float *row = lg + g * LP;
+      float mx = row[0];
+      for (uint32_t t = 1; t < LP; ++t) mx = fmaxf(mx, row[t]);
+      float sum = 0.f;
+      for (uint32_t t = 0; t < LP; ++t) sum += expf(row[t] - mx);
+      const float a = __fdiv_rn(expf(row[j] - mx), sum);
+      const int H = (int)shapes[2u * l], W = (int)shapes[2u * l + 1u];
+      const float2 rp = *reinterpret_cast<const float2 *>(refp + 2u * ((q0 + g) * (uint32_t)L + l));
+      // exactly the caller's arithmetic: reference + offset / (W, H), one rounding each
+      const float2 xy = make_float2(__fadd_rn(rp.x, __fdiv_rn(offv[r].x, (float)W)),
+                                    __fadd_rn(rp.y, __fdiv_rn(offv[r].y, (float)H)));
+      const uint32_t lrow = (uint32_t)lsi[l];
+      const Corner4<float> c = corner_setup<float>(xy.x, xy.y, H, W);
+      sk[g * pstride + j] = make_float4(c.k1 * a, c.k2 * a, c.k3 * a, c.k4 * a);
+      so[g * pstride + j] = make_uint4((lrow + (uint32_t)c.o1) * row_bytes, (lrow + (uint32_t)c.o2) * row_bytes,
+                                       (lrow + (uint32_t)c.o3) * row_bytes, (lrow + (uint32_t)c.o4) * row_bytes);
+    }
+  } else {
     const uint32_t nsamp = min(GP, nq - q0) * LP;
     for (uint32_t i = lane; i < nsamp; i += 64u) {
       const uint32_t g = i / LP, j = i - g * LP, l = j / (uint32_t)P;
@@ -1290,6 +1339,62 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
 
 }  // namespace binned
 
+// =======================================================================================
+// Row f3: the op's neighbours in the caller (ops/modules/ms_deform_attn.py:102-109) for the
+// BACKWARD of the fused boundary.  One thread per (image, query, head).
+//   prologue: loc = reference_point + offset / (W_l, H_l), aw = softmax(logits over L*P) into the
+//             workspace, for the backward kernels above (what the unfused caller keeps from its
+//             forward);
+//   epilogue: in place, grad_loc -> grad_offset = grad_loc / (W_l, H_l) and
+//             grad_aw -> grad_logit = aw * (grad_aw - sum_i aw_i * grad_aw_i).
+// =======================================================================================
+__global__ __launch_bounds__(256) void msda_fused_prologue_kernel(
+    const int64_t *__restrict__ shapes, const float *__restrict__ refp, const float *__restrict__ off,
+    const float *__restrict__ logits, int M, int L, int P, size_t npairs, float *__restrict__ loc,
+    float *__restrict__ aw) {
+  const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pair >= npairs) return;
+  const size_t qi = pair / (size_t)M;
+  const int LP = L * P;
+  const float *lg = logits + pair * (size_t)LP;
+  float mx = lg[0];
+  for (int t = 1; t < LP; ++t) mx = fmaxf(mx, lg[t]);
+  float sum = 0.f;
+  for (int t = 0; t < LP; ++t) sum += expf(lg[t] - mx);
+  for (int l = 0; l < L; ++l) {
+    const float H = (float)shapes[2 * l], W = (float)shapes[2 * l + 1];
+    const float rx = refp[2 * (qi * L + l)], ry = refp[2 * (qi * L + l) + 1];
+    for (int p = 0; p < P; ++p) {
+      const size_t s = pair * (size_t)LP + (size_t)(l * P + p);
+      loc[2 * s] = __fadd_rn(rx, __fdiv_rn(off[2 * s], W));
+      loc[2 * s + 1] = __fadd_rn(ry, __fdiv_rn(off[2 * s + 1], H));
+      aw[s] = __fdiv_rn(expf(lg[l * P + p] - mx), sum);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void msda_fused_epilogue_kernel(
+    const int64_t *__restrict__ shapes, const float *__restrict__ aw, int L, int P, size_t npairs,
+    float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
+  const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pair >= npairs) return;
+  const int LP = L * P;
+  const float *a = aw + pair * (size_t)LP;
+  float *ga = grad_aw + pair * (size_t)LP;
+  float dot = 0.f;
+  for (int t = 0; t < LP; ++t) dot = fmaf(a[t], ga[t], dot);
+  for (int l = 0; l < L; ++l) {
+    const float H = (float)shapes[2 * l], W = (float)shapes[2 * l + 1];
+    for (int p = 0; p < P; ++p) {
+      const int t = l * P + p;
+      const size_t s = pair * (size_t)LP + (size_t)t;
+      ga[t] = a[t] * (ga[t] - dot);
+      grad_loc[2 * s] = __fdiv_rn(grad_loc[2 * s], W);
+      grad_loc[2 * s + 1] = __fdiv_rn(grad_loc[2 * s + 1], H);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Host side.
 // ---------------------------------------------------------------------------------------
@@ -1406,8 +1511,8 @@ void launch_forward_d32(const VT *value, const int64_t *shapes, const int64_t *l
       aligned16(out)) {
     const uint32_t nq = (uint32_t)(npairs / (size_t)M), nunits = ((nq + GP - 1u) / GP) * (uint32_t)M;
     const uint32_t nblk = (nunits + 3u) / 4u;
-    hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT>), dim3(nblk), dim3(256), lds, st, value, shapes, lsi,
-                       loc, aw, S, M, L, Lq, P, nq, nunits, nblk, out);
+    hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT, false>), dim3(nblk), dim3(256), lds, st, value, shapes, lsi,
+                       loc, aw, (const float *)nullptr, S, M, L, Lq, P, nq, nunits, nblk, out);
     return;
   }
   const uint32_t nblk = (uint32_t)((npairs + 31) / 32);
@@ -1618,9 +1723,108 @@ int backward_bf16(const char *who, const uint16_t *value, const int64_t *shapes,
                               own_workspace, static_cast<hipStream_t>(stream));
 }
 
+
+// ---- row f3: fused boundary (fp32) ----
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *refp,
+                      const float *off, const float *logits, int N, int S, int M, int D, int L, int Lq,
+                      int P, float *out, void *stream) {
+  const char *who = "msda_fused_forward_f32";
+  if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
+  if ((size_t)N * Lq == 0) return MSDA_OK;
+  const size_t npairs = (size_t)N * Lq * M, limit = (size_t)1 << 30;
+  const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit && npairs * D < limit;
+  if (D != 32 || L * P > FWD_FUSED_MAX_LP || !small || !aligned16(value) || !aligned16(out) ||
+      (reinterpret_cast<uintptr_t>(off) & 7u) || (reinterpret_cast<uintptr_t>(refp) & 7u))
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "%s: needs channels == 32, num_levels * num_point <= %d, aligned tensors of < 2^30 "
+                "elements (use the unfused entry points otherwise)", who, FWD_FUSED_MAX_LP);
+  constexpr uint32_t GP = 64u / FwdLanes<float>::LPG;
+  const size_t lds = (size_t)4 * ((size_t)2 * GP * (size_t)(L * P + 1) * 16 + (((size_t)GP * L * P + 3) / 4) * 16);
+  const uint32_t nq = (uint32_t)((size_t)N * Lq), nunits = ((nq + GP - 1u) / GP) * (uint32_t)M;
+  const uint32_t nblk = (nunits + 3u) / 4u;
+  hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<float, true>), dim3(nblk), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), value, shapes, lsi, off, logits, refp, S, M, L, Lq, P,
+                     nq, nunits, nblk, out);
+  return check_launch(who);
+}
+
+size_t fused_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P) {
+  const size_t samples = (size_t)N * Lq * M * L * P;
+  size_t inner = 0;
+  if (binned_shape(N, S, M, D, L, Lq, P) && bwd_impl_choice() != 0)
+    inner = binned_workspace_bytes(N, S, M, L, Lq, P);
+  return align256(samples * 8) + align256(samples * 4) + align256(inner);
+}
+
+int fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *refp,
+                       const float *off, const float *logits, const float *grad_out, int N, int S, int M,
+                       int D, int L, int Lq, int P, float *grad_value, float *grad_off, float *grad_logits,
+                       void *workspace, size_t workspace_bytes, void *stream) {
+  const char *who = "msda_fused_backward_f32";
+  if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
+  const size_t need = fused_backward_workspace_bytes(N, S, M, D, L, Lq, P);
+  if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "%s: needs a 256-byte aligned device workspace of at least %zu bytes (got %zu)", who, need,
+                workspace ? workspace_bytes : (size_t)0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t npairs = (size_t)N * Lq * M, samples = npairs * L * P;
+  float *loc = static_cast<float *>(workspace);
+  float *aw = reinterpret_cast<float *>(static_cast<char *>(workspace) + align256(samples * 8));
+  void *inner = static_cast<char *>(workspace) + align256(samples * 8) + align256(samples * 4);
+  const size_t inner_bytes = need - align256(samples * 8) - align256(samples * 4);
+  const size_t nblk = (npairs + 255) / 256;
+  if (nblk > 0x7fffffffull) return fail(MSDA_ERR_INVALID_ARGUMENT, "%s: problem too large", who);
+  if (npairs) {
+    hipLaunchKernelGGL(msda_fused_prologue_kernel, dim3((unsigned)nblk), dim3(256), 0, st, shapes, refp, off,
+                       logits, M, L, P, npairs, loc, aw);
+    if (int rc = check_launch(who)) return rc;
+  }
+  if (int rc = backward_f32(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P, grad_value,
+                            grad_off, grad_logits, inner, inner_bytes, false, stream))
+    return rc;
+  if (npairs) {
+    hipLaunchKernelGGL(msda_fused_epilogue_kernel, dim3((unsigned)nblk), dim3(256), 0, st, shapes, aw, L, P,
+                       npairs, grad_off, grad_logits);
+    if (int rc = check_launch(who)) return rc;
+  }
+  return MSDA_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int msda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
+                           const int64_t *level_start_index, const float *reference_points,
+                           const float *sampling_offsets, const float *attn_logits, int batch,
+                           int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                           int num_point, float *output, void *stream) {
+  return fused_forward_f32(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                           attn_logits, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                           num_point, output, stream);
+}
+
+size_t msda_fused_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                           int num_levels, int num_query, int num_point) {
+  return fused_backward_workspace_bytes(batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                        num_point);
+}
+
+int msda_fused_backward_f32(const float *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const float *reference_points,
+                            const float *sampling_offsets, const float *attn_logits,
+                            const float *grad_output, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point, float *grad_value,
+                            float *grad_sampling_offsets, float *grad_attn_logits, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+  return fused_backward_f32(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                            attn_logits, grad_output, batch, spatial_size, num_heads, channels, num_levels,
+                            num_query, num_point, grad_value, grad_sampling_offsets, grad_attn_logits,
+                            workspace, workspace_bytes, stream);
+}
 
 #ifdef MSDA_PHASE_STAMPS
 // diagnostic build only: read (and clear) the per-phase cycle sums
@@ -1632,7 +1836,7 @@ int msda_debug_phase_cycles(unsigned long long *out16) {
 }
 #endif
 
-int msda_abi_version(void) { return 2; }
+int msda_abi_version(void) { return 3; }
 
 const char *msda_last_error(void) { return g_err; }
 

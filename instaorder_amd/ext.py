@@ -51,7 +51,12 @@ def _load():
     lib.msda_last_error.restype = ctypes.c_char_p
     lib.msda_launch_count.restype = ctypes.c_uint64
     lib.msda_abi_version.restype = _I
-    if lib.msda_abi_version() != 2:
+    lib.msda_fused_forward_f32.argtypes, lib.msda_fused_forward_f32.restype = [_P] * 6 + [_I] * 7 + [_P, _P], _I
+    lib.msda_fused_backward_f32.argtypes = [_P] * 7 + [_I] * 7 + [_P] * 4 + [ctypes.c_size_t, _P]
+    lib.msda_fused_backward_f32.restype = _I
+    lib.msda_fused_backward_workspace_bytes.argtypes = [_I] * 7
+    lib.msda_fused_backward_workspace_bytes.restype = ctypes.c_size_t
+    if lib.msda_abi_version() != 3:
         raise RuntimeError("libmsda_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -168,3 +173,82 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if rc != 0:
         _raise(lib, "ms_deform_attn_backward")
     return [grad_value, grad_sampling_loc, grad_attn_weight]
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused boundary (opt-in): the op plus the softmax and the
+# sampling-location arithmetic of its caller (reference ops/modules/ms_deform_attn.py:102-109).
+# ---------------------------------------------------------------------------------------------
+def fused_forward_supported(value, reference_points, num_levels, num_point):
+    """True when msda_fused_forward_f32 takes the call (else use the unfused functions)."""
+    return (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.shape[3] == 32
+            and reference_points.shape[-1] == 2 and num_levels * num_point <= 16)
+
+
+def _fused_common(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                  attn_logits):
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    named = (("value", value), ("spatial_shapes", spatial_shapes),
+             ("level_start_index", level_start_index), ("reference_points", reference_points),
+             ("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits))
+    _check_inputs(named)
+    if any(t.dtype != torch.float32 for t in (value, reference_points, sampling_offsets, attn_logits)):
+        raise RuntimeError("the fused MSDA entry points are fp32 only")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
+    if value.dim() != 4 or sampling_offsets.dim() != 6:
+        raise RuntimeError("expected value [N,S,M,D], sampling_offsets [N,Lq,M,L,P,2]")
+    n, s, m, d = value.shape
+    nl = spatial_shapes.shape[0]
+    lq, npt = sampling_offsets.shape[1], sampling_offsets.shape[4]
+    if (tuple(sampling_offsets.shape) != (n, lq, m, nl, npt, 2)
+            or attn_logits.numel() != n * lq * m * nl * npt
+            or tuple(reference_points.shape) != (n, lq, nl, 2)
+            or tuple(spatial_shapes.shape) != (nl, 2) or tuple(level_start_index.shape) != (nl,)):
+        raise RuntimeError("inconsistent fused MSDA argument shapes (reference_points must be "
+                           "[N,Lq,L,2])")
+    return n, s, m, d, nl, lq, npt
+
+
+def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points,
+                                 sampling_offsets, attn_logits):
+    """-> output [N, Lq, M*D] from the raw offsets [N,Lq,M,L,P,2] and logits [N,Lq,M,L*P]."""
+    n, s, m, d, nl, lq, npt = _fused_common(value, spatial_shapes, level_start_index,
+                                            reference_points, sampling_offsets, attn_logits)
+    lib = _load()
+    with torch.cuda.device(value.device):
+        output = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
+        rc = lib.msda_fused_forward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            reference_points.data_ptr(), sampling_offsets.data_ptr(), attn_logits.data_ptr(),
+            n, s, m, d, nl, lq, npt, output.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _raise(lib, "ms_deform_attn_fused_forward")
+    return output
+
+
+def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, reference_points,
+                                  sampling_offsets, attn_logits, grad_output):
+    """-> [grad_value, grad_sampling_offsets, grad_attn_logits]."""
+    n, s, m, d, nl, lq, npt = _fused_common(value, spatial_shapes, level_start_index,
+                                            reference_points, sampling_offsets, attn_logits)
+    if grad_output.dtype != value.dtype or grad_output.numel() != n * lq * m * d:
+        raise RuntimeError("grad_output must be [N, Lq, M*D] with value's dtype")
+    _check_inputs((("grad_output", grad_output),))
+    lib = _load()
+    with torch.cuda.device(value.device):
+        grad_value = torch.empty_like(value)
+        grad_offsets = torch.empty_like(sampling_offsets)
+        grad_logits = torch.empty_like(attn_logits)
+        nbytes = int(lib.msda_fused_backward_workspace_bytes(n, s, m, d, nl, lq, npt))
+        workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=value.device)
+        rc = lib.msda_fused_backward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            reference_points.data_ptr(), sampling_offsets.data_ptr(), attn_logits.data_ptr(),
+            grad_output.data_ptr(), n, s, m, d, nl, lq, npt, grad_value.data_ptr(),
+            grad_offsets.data_ptr(), grad_logits.data_ptr(), workspace.data_ptr(), nbytes,
+            torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _raise(lib, "ms_deform_attn_fused_backward")
+    return [grad_value, grad_offsets, grad_logits]

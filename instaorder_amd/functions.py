@@ -36,6 +36,42 @@ class MSDeformAttnFunction(Function):
         return grad_value.to(value.dtype), None, None, grad_sampling_loc, grad_attn_weight, None
 
 
+class MSDeformAttnFusedFunction(Function):
+    """Opt-in fused boundary: the op together with the softmax and the
+    sampling-location arithmetic of MSDeformAttn.forward (reference
+    ops/modules/ms_deform_attn.py:102-109).
+
+        out = MSDeformAttnFusedFunction.apply(value, spatial_shapes, level_start_index,
+                                              reference_points, sampling_offsets, attn_logits)
+
+    with reference_points [N,Lq,L,2], sampling_offsets [N,Lq,M,L,P,2] and attn_logits [N,Lq,M,L*P]
+    (the raw outputs of the module's two linears).  Saves the raw tensors, not locations/weights;
+    backward returns gradients for value, sampling_offsets and attn_logits (and for
+    reference_points when it requires one)."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                attn_logits):
+        output = ext.ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index,
+                                                  reference_points, sampling_offsets, attn_logits)
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, reference_points,
+                              sampling_offsets, attn_logits)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, level_start, ref, offsets, logits = ctx.saved_tensors
+        grad_value, grad_offsets, grad_logits = ext.ms_deform_attn_fused_backward(
+            value, shapes, level_start, ref, offsets, logits, grad_output.contiguous())
+        grad_ref = None
+        if ctx.needs_input_grad[3]:
+            # d loc / d ref = 1 and grad_offsets = grad_loc / (W_l, H_l)
+            wh = shapes.flip(-1).to(grad_offsets.dtype)                       # (W_l, H_l)
+            grad_ref = (grad_offsets * wh[None, None, None, :, None, :]).sum(dim=(2, 4))
+        return grad_value, None, None, grad_ref, grad_offsets, grad_logits
+
+
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
     """CPU-tensor path of the reference's ops/functions module (ms_deform_attn_func.py:52-72):
     per level, bilinear ``grid_sample`` (zero padding, align_corners=False) of the level's map

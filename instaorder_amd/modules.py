@@ -15,7 +15,8 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
-from .functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
+from . import ext
+from .functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, ms_deform_attn_core_pytorch
 
 
 def _is_power_of_2(n):
@@ -33,6 +34,9 @@ class MSDeformAttn(nn.Module):
             warnings.warn("MSDeformAttn: a per-head dimension of 32 takes the fast HIP kernels; "
                           "other sizes run the generic ones.")
         self.im2col_step = 128                      # ms_deform_attn.py:52
+        # opt-in (not reference behaviour): hand the raw offsets / logits to the fused entry points
+        # (softmax and location arithmetic inside the HIP kernels) when the call qualifies
+        self.fused_prologue = False
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -73,6 +77,11 @@ class MSDeformAttn(nn.Module):
         value = value.view(n, len_in, self.n_heads, self.d_model // self.n_heads)
         offsets = self.sampling_offsets(query).view(n, len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(n, len_q, self.n_heads, self.n_levels * self.n_points)
+        if self.fused_prologue and ext.fused_forward_supported(value, reference_points, self.n_levels,
+                                                               self.n_points):
+            output = MSDeformAttnFusedFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                                     reference_points.contiguous(), offsets, weights)
+            return self.output_proj(output)
         weights = F.softmax(weights, -1).view(n, len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)

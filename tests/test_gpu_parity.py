@@ -483,3 +483,117 @@ def test_backward_run_to_run_agreement(msda):
     b = msda.ms_deform_attn_backward(*args)
     for x, y in zip(a, b):
         assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < ORDER_TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused boundary: softmax + sampling-location arithmetic of the
+# caller (reference ops/modules/ms_deform_attn.py:102-109) inside the kernels.  Checked against
+# the same arithmetic in PyTorch feeding the drop-in entry points.
+# ---------------------------------------------------------------------------------------------
+def _fused_inputs(batch, shapes, heads, points, num_query=None, seed=5):
+    from instaorder_amd import synthetic
+    g = torch.Generator().manual_seed(seed)
+    inp = synthetic.make_inputs(batch, shapes, heads=heads, channels=32, points=points, dist="uniform",
+                                seed=seed, **({} if num_query is None else {"num_query": num_query}))
+    lq, nl = inp["grad_output"].shape[1], len(shapes)
+    ref = torch.rand((batch, lq, nl, 2), generator=g)
+    off = 3.0 * torch.randn((batch, lq, heads, nl, points, 2), generator=g)      # pixels
+    logits = 2.0 * torch.randn((batch, lq, heads, nl * points), generator=g)
+    return inp, ref, off, logits
+
+
+def _unfused_reference(msda, value, shapes, lsi, ref, off, logits, go):
+    """The module's own arithmetic (modules.py / ms_deform_attn.py:102-109) + the drop-in op."""
+    from instaorder_amd import MSDeformAttnFunction
+    n, lq, m, nl, p, _ = off.shape
+    value, off, logits = (t.detach().clone().requires_grad_(True) for t in (value, off, logits))
+    aw = torch.softmax(logits, -1).view(n, lq, m, nl, p)
+    normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    loc = ref[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, aw, 128)
+    out.backward(go)
+    return out.detach(), value.grad, off.grad, logits.grad
+
+
+@pytest.mark.parametrize("shapes,heads,points,num_query,batch", [
+    ([(8, 8), (16, 16), (32, 32)], 8, 4, None, 2),        # the encoder's shape
+    ([(7, 9), (5, 3)], 3, 3, 37, 3),                      # ragged: partial waves, odd levels
+    ([(12, 20)], 2, 1, 5, 1),                             # one level, one point
+])
+def test_fused_entry_points_match_unfused(msda, shapes, heads, points, num_query, batch):
+    from instaorder_amd import ext
+    from instaorder_amd.functions import MSDeformAttnFusedFunction
+    inp, ref, off, logits = _fused_inputs(batch, shapes, heads, points, num_query)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    ref, off, logits = ref.cuda(), off.cuda(), logits.cuda()
+    go = dev["grad_output"]
+    o_ref, gv_ref, goff_ref, glog_ref = _unfused_reference(
+        msda, dev["value"], dev["spatial_shapes"], dev["level_start_index"], ref, off, logits, go)
+    value = dev["value"].clone().requires_grad_(True)
+    off_f, logits_f = off.clone().requires_grad_(True), logits.clone().requires_grad_(True)
+    before = ext.launch_count()
+    out = MSDeformAttnFusedFunction.apply(value, dev["spatial_shapes"], dev["level_start_index"], ref,
+                                          off_f, logits_f)
+    out.backward(go)
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 4, "fused HIP kernels were not launched"
+    n = lambda t: t.detach().cpu().numpy()
+    assert rel_err(n(out), n(o_ref)) < FWD_TOL_F32
+    assert rel_err(n(value.grad), n(gv_ref)) < GRAD_TOL_F32
+    assert rel_err(n(off_f.grad), n(goff_ref)) < GRAD_TOL_F32
+    assert rel_err(n(logits_f.grad), n(glog_ref)) < GRAD_TOL_F32
+
+
+def test_fused_reference_point_gradient_and_limits(msda):
+    from instaorder_amd import ext
+    from instaorder_amd.functions import MSDeformAttnFusedFunction
+    shapes = [(6, 10), (3, 5)]
+    inp, ref, off, logits = _fused_inputs(2, shapes, 4, 2, 11, seed=9)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    ss, lsi, go = dev["spatial_shapes"], dev["level_start_index"], dev["grad_output"]
+    # gradient of the reference points: against autograd through the unfused arithmetic
+    ref_a = ref.cuda().requires_grad_(True)
+    normalizer = torch.stack([ss[..., 1], ss[..., 0]], -1)
+    loc = ref_a[:, :, None, :, None, :] + off.cuda() / normalizer[None, None, None, :, None, :]
+    from instaorder_amd import MSDeformAttnFunction
+    aw = torch.softmax(logits.cuda(), -1).view(2, 11, 4, 2, 2)
+    MSDeformAttnFunction.apply(dev["value"], ss, lsi, loc, aw, 128).backward(go)
+    ref_f = ref.cuda().requires_grad_(True)
+    MSDeformAttnFusedFunction.apply(dev["value"], ss, lsi, ref_f, off.cuda(), logits.cuda()).backward(go)
+    assert rel_err(ref_f.grad.cpu().numpy(), ref_a.grad.cpu().numpy()) < GRAD_TOL_F32
+    # L * P > 16 is refused by the fused forward (callers fall back to the unfused entry points)
+    inp2, ref2, off2, logits2 = _fused_inputs(1, [(4, 4), (4, 4), (4, 4), (4, 4), (4, 4)], 2, 4, 3)
+    d2 = {k: v.cuda() for k, v in inp2.items()}
+    with pytest.raises(RuntimeError, match="num_levels \\* num_point <= 16"):
+        ext.ms_deform_attn_fused_forward(d2["value"], d2["spatial_shapes"], d2["level_start_index"],
+                                         ref2.cuda(), off2.cuda(), logits2.cuda())
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ext.ms_deform_attn_fused_forward(inp2["value"], inp2["spatial_shapes"], inp2["level_start_index"],
+                                         ref2, off2, logits2)
+
+
+def test_module_fused_prologue_matches_default(msda):
+    """MSDeformAttn(fused_prologue=True) == the default module: output and parameter gradients."""
+    from instaorder_amd import MSDeformAttn
+    torch.manual_seed(0)
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    ss = torch.tensor(shapes, dtype=torch.int64).cuda()
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    s = int(ss.prod(1).sum())
+    mod = MSDeformAttn(256, 3, 8, 4).cuda()
+    with torch.no_grad():                                 # leave the degenerate initialisation
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.2)
+    query, src = torch.randn(2, s, 256).cuda(), torch.randn(2, s, 256).cuda()
+    ref = torch.rand(2, s, 3, 2).cuda()
+    outs, grads = [], []
+    for fused in (False, True):
+        mod.fused_prologue = fused
+        mod.zero_grad()
+        out = mod(query, ref, src, ss, lsi)
+        out.square().mean().backward()
+        outs.append(out.detach().cpu().numpy())
+        grads.append({k: p.grad.detach().cpu().numpy().copy() for k, p in mod.named_parameters()})
+    assert rel_err(outs[1], outs[0]) < FWD_TOL_F32
+    for k in grads[0]:
+        assert rel_err(grads[1][k], grads[0][k]) < GRAD_TOL_F32, k

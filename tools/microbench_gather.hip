@@ -104,6 +104,48 @@ void depth(const char *d, float *o, uint32_t rows, double ghz, int cus) {
          NL * WPE * 4, rows, ms * 1e-3 * ghz * 1e9 / (row_loads / cus), row_loads * 128 / (ms * 1e-3) / 1e12);
 }
 
+// How does the cost of a gather wave-instruction depend on the number of ACTIVE lane groups?
+// ACT of the 8 groups of a wave (8 lanes x dwordx4 each) issue the load, the others are masked off.
+template <int ACT>
+__global__ __launch_bounds__(256) void gather_masked(const char *__restrict__ base, uint32_t row_mask,
+                                                     int iters, float *out) {
+  const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, sub = lane & 7u;
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  uint32_t h = (wave * 8u + grp) * 2654435761u + 12345u;
+  float acc = 0.f;
+  if (grp < (uint32_t)ACT) {
+    for (int it = 0; it < iters; ++it) {
+      float4 v[NLOAD];
+#pragma unroll
+      for (int j = 0; j < NLOAD; ++j) {
+        h = h * 1664525u + 1013904223u;
+        const uint32_t row = (h >> 9) & row_mask;
+        v[j] = *reinterpret_cast<const float4 *>(base + (size_t)row * 128u + sub * 16u);
+      }
+#pragma unroll
+      for (int j = 0; j < NLOAD; ++j) acc += sum(v[j]);
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int ACT>
+void masked(const char *d, float *o, uint32_t rows, double ghz, int cus) {
+  const int blocks = cus * 8, iters = 256;
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL((gather_masked<ACT>), dim3(blocks), dim3(256), 0, 0, d, rows - 1, iters, o);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  hipLaunchKernelGGL((gather_masked<ACT>), dim3(blocks), dim3(256), 0, 0, d, rows - 1, iters, o);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+  const double instr = (double)blocks * 4 * iters * NLOAD;
+  printf("masked: %d of 8 lane groups active  rows=%6u  %6.2f clk per wave-instruction per CU  (%5.2f clk per active row)\n", ACT, rows,
+         ms * 1e-3 * ghz * 1e9 / (instr / cus), ms * 1e-3 * ghz * 1e9 / (instr / cus) / ACT);
+}
+
 int main() {
   hipDeviceProp_t p;
   CHECK(hipGetDeviceProperties(&p, 0));
@@ -121,6 +163,10 @@ int main() {
     run<32, 0>("32 lanes x dword, random row per group", d, o, rows, ghz, cus);
     run<8, 1>("8 lanes x dwordx4, 8 consecutive rows per wave", d, o, rows, ghz, cus);
     run<8, 2>("8 lanes x dwordx4, neighbouring groups share a row", d, o, rows, ghz, cus);
+  }
+  for (uint32_t rows : {128u, 16384u}) {
+    masked<8>(d, o, rows, ghz, cus); masked<6>(d, o, rows, ghz, cus); masked<4>(d, o, rows, ghz, cus);
+    masked<2>(d, o, rows, ghz, cus); masked<1>(d, o, rows, ghz, cus);
   }
   // in-flight depth: waves per SIMD x loads per wave, 8 lanes x dwordx4, random rows
   for (uint32_t rows : {128u, 16384u}) {
