@@ -1348,50 +1348,70 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
 //   epilogue: in place, grad_loc -> grad_offset = grad_loc / (W_l, H_l) and
 //             grad_aw -> grad_logit = aw * (grad_aw - sum_i aw_i * grad_aw_i).
 // =======================================================================================
+constexpr int FUSED_PB = 64;        // pairs per workgroup of the prologue / epilogue kernels
+constexpr int FUSED_MAX_LP = 64;    // L * P they stage in LDS
+
+// Coalesced: a workgroup takes FUSED_PB consecutive pairs = FUSED_PB * L*P consecutive samples;
+// the per-pair softmax statistics go through LDS, everything else is one sample per thread.
 __global__ __launch_bounds__(256) void msda_fused_prologue_kernel(
     const int64_t *__restrict__ shapes, const float *__restrict__ refp, const float *__restrict__ off,
     const float *__restrict__ logits, int M, int L, int P, size_t npairs, float *__restrict__ loc,
     float *__restrict__ aw) {
-  const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (pair >= npairs) return;
-  const size_t qi = pair / (size_t)M;
-  const int LP = L * P;
-  const float *lg = logits + pair * (size_t)LP;
-  float mx = lg[0];
-  for (int t = 1; t < LP; ++t) mx = fmaxf(mx, lg[t]);
-  float sum = 0.f;
-  for (int t = 0; t < LP; ++t) sum += expf(lg[t] - mx);
-  for (int l = 0; l < L; ++l) {
+  __shared__ float s_lg[FUSED_PB * FUSED_MAX_LP];
+  __shared__ float s_mx[FUSED_PB], s_sum[FUSED_PB];
+  const int LP = L * P, tid = threadIdx.x;
+  const size_t pair0 = (size_t)blockIdx.x * FUSED_PB;
+  const int npb = (int)min((size_t)FUSED_PB, npairs - pair0), nsb = npb * LP;
+  const size_t s0 = pair0 * (size_t)LP;
+  for (int i = tid; i < nsb; i += 256) s_lg[i] = logits[s0 + i];
+  __syncthreads();
+  if (tid < npb) {
+    const float *lg = s_lg + tid * LP;
+    float mx = lg[0];
+    for (int t = 1; t < LP; ++t) mx = fmaxf(mx, lg[t]);
+    float sum = 0.f;
+    for (int t = 0; t < LP; ++t) sum += expf(lg[t] - mx);
+    s_mx[tid] = mx;
+    s_sum[tid] = sum;
+  }
+  __syncthreads();
+  for (int i = tid; i < nsb; i += 256) {
+    const int pl = i / LP, j = i - pl * LP, l = j / P;
+    const size_t qi = (pair0 + pl) / (size_t)M;
     const float H = (float)shapes[2 * l], W = (float)shapes[2 * l + 1];
-    const float rx = refp[2 * (qi * L + l)], ry = refp[2 * (qi * L + l) + 1];
-    for (int p = 0; p < P; ++p) {
-      const size_t s = pair * (size_t)LP + (size_t)(l * P + p);
-      loc[2 * s] = __fadd_rn(rx, __fdiv_rn(off[2 * s], W));
-      loc[2 * s + 1] = __fadd_rn(ry, __fdiv_rn(off[2 * s + 1], H));
-      aw[s] = __fdiv_rn(expf(lg[l * P + p] - mx), sum);
-    }
+    const float2 rp = *reinterpret_cast<const float2 *>(refp + 2 * (qi * L + l));
+    const float2 o = *reinterpret_cast<const float2 *>(off + 2 * (s0 + i));
+    *reinterpret_cast<float2 *>(loc + 2 * (s0 + i)) =
+        make_float2(__fadd_rn(rp.x, __fdiv_rn(o.x, W)), __fadd_rn(rp.y, __fdiv_rn(o.y, H)));
+    aw[s0 + i] = __fdiv_rn(expf(s_lg[i] - s_mx[pl]), s_sum[pl]);
   }
 }
 
 __global__ __launch_bounds__(256) void msda_fused_epilogue_kernel(
     const int64_t *__restrict__ shapes, const float *__restrict__ aw, int L, int P, size_t npairs,
     float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
-  const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (pair >= npairs) return;
-  const int LP = L * P;
-  const float *a = aw + pair * (size_t)LP;
-  float *ga = grad_aw + pair * (size_t)LP;
-  float dot = 0.f;
-  for (int t = 0; t < LP; ++t) dot = fmaf(a[t], ga[t], dot);
-  for (int l = 0; l < L; ++l) {
+  __shared__ float s_prod[FUSED_PB * FUSED_MAX_LP];
+  __shared__ float s_dot[FUSED_PB];
+  const int LP = L * P, tid = threadIdx.x;
+  const size_t pair0 = (size_t)blockIdx.x * FUSED_PB;
+  const int npb = (int)min((size_t)FUSED_PB, npairs - pair0), nsb = npb * LP;
+  const size_t s0 = pair0 * (size_t)LP;
+  for (int i = tid; i < nsb; i += 256) s_prod[i] = aw[s0 + i] * grad_aw[s0 + i];
+  __syncthreads();
+  if (tid < npb) {
+    float dot = 0.f;
+    for (int t = 0; t < LP; ++t) dot += s_prod[tid * LP + t];
+    s_dot[tid] = dot;
+  }
+  __syncthreads();
+  for (int i = tid; i < nsb; i += 256) {
+    const int pl = i / LP, j = i - pl * LP, l = j / P;
     const float H = (float)shapes[2 * l], W = (float)shapes[2 * l + 1];
-    for (int p = 0; p < P; ++p) {
-      const int t = l * P + p;
-      const size_t s = pair * (size_t)LP + (size_t)t;
-      ga[t] = a[t] * (ga[t] - dot);
-      grad_loc[2 * s] = __fdiv_rn(grad_loc[2 * s], W);
-      grad_loc[2 * s + 1] = __fdiv_rn(grad_loc[2 * s + 1], H);
-    }
+    // aw * (grad_aw - dot)
+    grad_aw[s0 + i] = s_prod[i] - aw[s0 + i] * s_dot[pl];
+    float2 *g = reinterpret_cast<float2 *>(grad_loc + 2 * (s0 + i));
+    const float2 v = *g;
+    *g = make_float2(__fdiv_rn(v.x, W), __fdiv_rn(v.y, H));
   }
 }
 
@@ -1775,8 +1795,10 @@ int fused_backward_f32(const float *value, const int64_t *shapes, const int64_t 
   float *aw = reinterpret_cast<float *>(static_cast<char *>(workspace) + align256(samples * 8));
   void *inner = static_cast<char *>(workspace) + align256(samples * 8) + align256(samples * 4);
   const size_t inner_bytes = need - align256(samples * 8) - align256(samples * 4);
-  const size_t nblk = (npairs + 255) / 256;
+  const size_t nblk = (npairs + FUSED_PB - 1) / FUSED_PB;
   if (nblk > 0x7fffffffull) return fail(MSDA_ERR_INVALID_ARGUMENT, "%s: problem too large", who);
+  if (L * P > FUSED_MAX_LP)
+    return fail(MSDA_ERR_INVALID_ARGUMENT, "%s: num_levels * num_point must be <= %d", who, FUSED_MAX_LP);
   if (npairs) {
     hipLaunchKernelGGL(msda_fused_prologue_kernel, dim3((unsigned)nblk), dim3(256), 0, st, shapes, refp, off,
                        logits, M, L, P, npairs, loc, aw);

@@ -46,6 +46,10 @@ def run(args):
     device = torch.device("cuda", local) if torch.cuda.is_available() and not args.cpu else torch.device("cpu")
     shapes = synthetic.encoder_shapes(args.image)
     enc = build_encoder(len(shapes), args.freeze_base).to(device)
+    if args.fused:      # row f3: softmax + sampling-location arithmetic inside the MSDA kernels
+        for mod in enc.modules():
+            if hasattr(mod, "fused_prologue"):
+                mod.fused_prologue = True
     model = enc
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -95,4 +99,6 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--all-trainable", dest="freeze_base", action="store_false")
+    ap.add_argument("--fused", action="store_true",
+                    help="MSDeformAttn.fused_prologue: the fused entry points (SURVEY section 8, row f3)")
     run(ap.parse_args())
