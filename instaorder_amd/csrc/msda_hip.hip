@@ -663,16 +663,24 @@ struct PointTiles {
   bool in;
 };
 __device__ __forceinline__ PointTiles point_tiles(float lx, float ly, int H, int W) {
-  const Corner4<float> g = corner_setup<float>(lx, ly, H, W);
+  // the part of corner_setup that decides WHERE a sample lands: same fused multiply-add, same gate,
+  // same floor -- bit-identical h0 / w0 -- without the weights
+  const float fH = (float)H, fW = (float)W;
+  const float h_im = pix_coord(ly, fH), w_im = pix_coord(lx, fW);
   PointTiles t;
-  t.in = g.in;
-  const int ra = g.h0 >= 0 ? g.h0 : g.h0 + 1, rb = g.h0 + 1 <= H - 1 ? g.h0 + 1 : g.h0;
-  const int ca = g.w0 >= 0 ? g.w0 : g.w0 + 1, cb = g.w0 + 1 <= W - 1 ? g.w0 + 1 : g.w0;
-  t.tya = ra / T;
-  t.tyb = rb / T;
-  t.txa = ca / T;
-  t.txb = cb / T;
+  t.in = (h_im > -1.f) && (w_im > -1.f) && (h_im < fH) && (w_im < fW);
+  const int h0 = (int)floorf(t.in ? h_im : 0.f), w0 = (int)floorf(t.in ? w_im : 0.f);
+  // first / last in-level row and column of the 2 x 2 footprint (h0, w0 >= -1 when the gate is open)
+  t.tya = (uint32_t)max(h0, 0) / (uint32_t)T;
+  t.tyb = (uint32_t)min(h0 + 1, H - 1) / (uint32_t)T;
+  t.txa = (uint32_t)max(w0, 0) / (uint32_t)T;
+  t.txb = (uint32_t)min(w0 + 1, W - 1) / (uint32_t)T;
   return t;
+}
+
+// i / d for i < 2^32 and d < 2^8, with magic = ceil(2^40 / d) from the host (exact: i * d < 2^40)
+__device__ __forceinline__ uint32_t div_magic(uint32_t i, uint64_t magic) {
+  return (uint32_t)(((uint64_t)i * magic) >> 40);
 }
 
 // Calls f(tile_y, tile_x, mask) once per list the quad belongs to.  When the quad's points
@@ -719,7 +727,8 @@ constexpr int DESC_MAX_TILE = 1 << 15;
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_NT) void msda_bwd_bin_kernel(
     const int64_t *__restrict__ shapes, const float *__restrict__ loc, int N, int M, int L, int Lq,
-    int P, uint32_t qpi, uint32_t bpi, uint32_t key_cap, uint32_t *__restrict__ counts,
+    int P, uint32_t qpi, uint32_t bpi, uint64_t magic_ml, uint64_t magic_l, uint32_t key_cap,
+    uint32_t *__restrict__ counts,
     uint32_t *__restrict__ desc, uint32_t *__restrict__ entries, float *__restrict__ grad_loc,
     float *__restrict__ grad_aw) {
   __shared__ uint32_t s_hist[KCAP];
@@ -736,9 +745,9 @@ __global__ __launch_bounds__(BIN_NT) void msda_bwd_bin_kernel(
   const uint32_t q0 = n * qpi;                          // first quad of this image
 
   auto decode = [&](uint32_t i, uint32_t &q, uint32_t &m, uint32_t &l) {
-    q = i / ML;
+    q = div_magic(i, magic_ml);
     const uint32_t r = i - q * ML;
-    m = r / (uint32_t)L;
+    m = div_magic(r, magic_l);
     l = r - m * (uint32_t)L;
   };
   // quad i of the image -> its points' tiles
@@ -1615,6 +1624,7 @@ bool binned_shape(int N, int S, int M, int D, int L, int Lq, int P) {
   if (!(D == 32 && P <= binned::MAXP && L <= binned::MAXL && N > 0 && S > 0 && Lq > 0)) return false;
   const size_t npairs = (size_t)N * Lq * M, limit = (size_t)1 << 30;
   return (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit && npairs * D < limit &&
+         (size_t)Lq * M * L * (size_t)(M * L) < ((size_t)1 << 40) &&            // div_magic of the binning kernels
          (size_t)N * Lq < ((size_t)1 << 28) &&                                   // entry = pair-less id << 4 | mask
          npairs * L * binned::MAX_ENTRIES_PER_QUAD < ((size_t)1 << 32);         // 32-bit list positions
 }
@@ -1653,16 +1663,18 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
   hipLaunchKernelGGL(binned::msda_bwd_bin_zero_kernel, dim3(cus), dim3(256), 0, st, shapes, N, M, L,
                      key_cap, counts);
   if (int rc = check_launch(who)) return rc;
+  const uint64_t magic_ml = (((uint64_t)1 << 40) + (uint64_t)(M * L) - 1) / (uint64_t)(M * L);
+  const uint64_t magic_l = (((uint64_t)1 << 40) + (uint64_t)L - 1) / (uint64_t)L;
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<false>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, desc, entries,
-                     grad_loc, grad_aw);
+                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
+                     entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, N, M, L,
                      key_cap, counts, offs);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<true>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, key_cap, counts, desc, entries,
-                     grad_loc, grad_aw);
+                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
+                     entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_binned_kernel<VT>, dim3(2 * cus), dim3(binned::NT), 0, st,
                      grad_out, value, shapes, lsi, loc, aw, offs, entries, work, key_cap, N, S, M, L,
