@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ aw, const float *__restrict__ refp, int S, int M, int L, int Lq, int P,
-    uint32_t nq, uint32_t nunits, uint32_t nblocks, VT *__restrict__ out) {
+    uint32_t nq, uint32_t nunits, uint32_t nblocks, bool wide, VT *__restrict__ out) {
   constexpr uint32_t LPG = FwdLanes<VT>::LPG, GP = 64u / LPG, CH = FwdLanes<VT>::CH;
   extern __shared__ float4 s_dyn[];
   const uint32_t LP = (uint32_t)(L * P);
@@ -372,17 +372,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   } else {
     const uint32_t nsamp = min(GP, nq - q0) * LP;
-    for (uint32_t i = lane; i < nsamp; i += 64u) {
-      const uint32_t g = i / LP, j = i - g * LP, l = j / (uint32_t)P;
-      const uint32_t s = ((q0 + g) * (uint32_t)M + m) * LP + j;
-      const float2 xy = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(loc) + s * 8u);
-      const float a = aw[s];
+    auto one = [&](uint32_t g, uint32_t j, float x, float y, float a) {
+      const uint32_t l = j / (uint32_t)P;
       const int H = (int)shapes[2u * l], W = (int)shapes[2u * l + 1u];
       const uint32_t lrow = (uint32_t)lsi[l];
-      const Corner4<float> c = corner_setup<float>(xy.x, xy.y, H, W);
+      const Corner4<float> c = corner_setup<float>(x, y, H, W);
       sk[g * pstride + j] = make_float4(c.k1 * a, c.k2 * a, c.k3 * a, c.k4 * a);
       so[g * pstride + j] = make_uint4((lrow + (uint32_t)c.o1) * row_bytes, (lrow + (uint32_t)c.o2) * row_bytes,
                                        (lrow + (uint32_t)c.o3) * row_bytes, (lrow + (uint32_t)c.o4) * row_bytes);
+    };
+    if ((LP & 1u) == 0u && wide) {
+      // two samples per lane: one 16-B location load and one 8-B weight load (a wave-instruction
+      // costs the vector L1 the same ~16 clk whatever its width: half as many of them)
+      for (uint32_t i = 2u * lane; i < nsamp; i += 128u) {
+        const uint32_t g = i / LP, j = i - g * LP;
+        const uint32_t s = ((q0 + g) * (uint32_t)M + m) * LP + j;
+        const float4 xy = ld16(loc, s * 8u);
+        const float2 a = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(aw) + s * 4u);
+        one(g, j, xy.x, xy.y, a.x);
+        one(g, j + 1u, xy.z, xy.w, a.y);
+      }
+    } else {
+      for (uint32_t i = lane; i < nsamp; i += 64u) {
+        const uint32_t g = i / LP, j = i - g * LP;
+        const uint32_t s = ((q0 + g) * (uint32_t)M + m) * LP + j;
+        const float2 xy = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(loc) + s * 8u);
+        one(g, j, xy.x, xy.y, aw[s]);
+      }
     }
   }
   // the region is private to the wave: order its LDS writes before the reads below, no s_barrier
@@ -1541,7 +1557,8 @@ void launch_forward_d32(const VT *value, const int64_t *shapes, const int64_t *l
     const uint32_t nq = (uint32_t)(npairs / (size_t)M), nunits = ((nq + GP - 1u) / GP) * (uint32_t)M;
     const uint32_t nblk = (nunits + 3u) / 4u;
     hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT, false>), dim3(nblk), dim3(256), lds, st, value, shapes, lsi,
-                       loc, aw, (const float *)nullptr, S, M, L, Lq, P, nq, nunits, nblk, out);
+                       loc, aw, (const float *)nullptr, S, M, L, Lq, P, nq, nunits, nblk,
+                       aligned16(loc) && (reinterpret_cast<uintptr_t>(aw) & 7u) == 0, out);
     return;
   }
   const uint32_t nblk = (uint32_t)((npairs + 31) / 32);
@@ -1778,7 +1795,7 @@ int fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *
   const uint32_t nblk = (nunits + 3u) / 4u;
   hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<float, true>), dim3(nblk), dim3(256), lds,
                      static_cast<hipStream_t>(stream), value, shapes, lsi, off, logits, refp, S, M, L, Lq, P,
-                     nq, nunits, nblk, out);
+                     nq, nunits, nblk, false, out);
   return check_launch(who);
 }
 
