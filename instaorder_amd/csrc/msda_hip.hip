@@ -966,7 +966,11 @@ __global__ __launch_bounds__(1024) void msda_bwd_bin_scan_kernel(const int64_t *
 struct Item {
   uint32_t n, m, list0, total, nchunks, lrow;   // lrow: value row of the level's first pixel
   int l, H, W, y0, x0, th, tw;
+  bool split;                                   // one of several parts of its tile's list
 };
+
+constexpr int SPLIT_TARGET_CHUNKS = 6;          // chunks a part of a split list should get
+constexpr int SPLIT_MAX_PARTS = 16;
 
 struct Next {          // the part of an Item that fetching its chunks needs
   uint32_t m;
@@ -980,7 +984,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ aw,
     const uint32_t *__restrict__ offs, const uint32_t *__restrict__ entries,
-    uint32_t *__restrict__ work, uint32_t key_cap, int N, int S, int M, int L, int P,
+    uint32_t *__restrict__ work, uint32_t key_cap, int N, int S, int M, int L, int P, int split_enable,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
   __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
   __shared__ float4 s_go[(CE + 1) * 8];     // grad_output rows of this chunk's entries + a zero row
@@ -990,7 +994,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   __shared__ uint32_t s_cnt[2][TP + 64];    // contributions per pixel, by chunk parity (+ dummies)
   __shared__ uint32_t s_hcount[2];
   __shared__ uint32_t s_pos[2];             // queue positions handed out to this workgroup
-  __shared__ int s_ord[MAXL], s_pbase[MAXL + 1];
+  __shared__ int s_ord[MAXL], s_pbase[MAXL + 1], s_parts[MAXL];
   __shared__ Levels lv;
 
   const int tid = threadIdx.x;
@@ -1009,10 +1013,22 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
           s_ord[j] = a;
         }
       }
+    // Small batches (the host sets split_enable and has zero-filled grad_value): the kernel would
+    // run as long as its longest list, so the lists of a level whose tiles average more than
+    // SPLIT_TARGET_CHUNKS chunks are cut into parts -- queue positions of their own, taken by
+    // different workgroups, which ADD their partial tile sums with float atomics.
     int pb = 0;
     for (int i = 0; i < L; ++i) {
+      const int l = s_ord[i], tiles = lv.toff[l + 1] - lv.toff[l];
+      int parts = 1;
+      if (split_enable && (uint64_t)N * (uint32_t)lv.toff[L] * (uint32_t)M <= key_cap) {
+        const uint32_t ents = offs[(uint32_t)lv.toff[l + 1] * (uint32_t)M] - offs[(uint32_t)lv.toff[l] * (uint32_t)M];   // image 0
+        const uint32_t avg_chunks = ents / ((uint32_t)(tiles * M) * (uint32_t)CE);
+        parts = min(max((int)(avg_chunks / SPLIT_TARGET_CHUNKS), 1), SPLIT_MAX_PARTS);
+      }
+      s_parts[i] = parts;
       s_pbase[i] = pb;
-      pb += N * M * (lv.toff[s_ord[i] + 1] - lv.toff[s_ord[i]]);
+      pb += N * M * tiles * parts;
     }
     s_pbase[L] = pb;
     s_pos[0] = gridDim.x + atomicAdd(work, 1u);          // this workgroup's second item
@@ -1022,24 +1038,40 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   __syncthreads();
   const uint32_t I_img = (uint32_t)uni(lv.toff[L]) * (uint32_t)M;
   if ((uint64_t)N * I_img > key_cap) return;
-  const uint32_t total_items = (uint32_t)N * I_img;
+  const uint32_t total_items = (uint32_t)uni(s_pbase[L]);       // queue positions: items, or parts of items
   if (blockIdx.x >= total_items) return;
   MSDA_STAMP_DECL
 
   const uint32_t slot = (uint32_t)tid >> 2, p = (uint32_t)tid & 3u;      // exam: entry slot, point
   const uint32_t gslot = (uint32_t)tid >> 3, gsub = (uint32_t)tid & 7u;   // rows gslot, gslot + 64
 
-  // queue position -> item index (the numbering of the lists: image, level, tile, head)
-  auto item_at = [&](uint32_t pos) -> uint32_t {
+  // queue position -> item index (the numbering of the lists: image, level, tile, head) and which
+  // part of how many of its list
+  auto item_at = [&](uint32_t pos, uint32_t &part, uint32_t &parts) -> uint32_t {
     int j = 0;
     while (j + 1 < L && (int)pos >= uni(s_pbase[j + 1])) ++j;
     const int l = uni(s_ord[j]);
-    const uint32_t r = pos - (uint32_t)uni(s_pbase[j]);
+    parts = (uint32_t)uni(s_parts[j]);
+    const uint32_t rp = pos - (uint32_t)uni(s_pbase[j]);
+    const uint32_t r = rp / parts;
+    part = rp - r * parts;
     const uint32_t per = (uint32_t)(uni(lv.toff[l + 1]) - uni(lv.toff[l])) * (uint32_t)M;   // items per image
     const uint32_t n = r / per;
     return n * I_img + (uint32_t)uni(lv.toff[l]) * (uint32_t)M + (r - n * per);
   };
-  auto decode = [&](uint32_t item) -> Item {
+  // the slice of an item's list that part `part` of `parts` takes: whole chunks, equal shares
+  auto slice = [&](uint32_t part, uint32_t parts, uint32_t &list0, uint32_t &total) {
+    if (parts > 1u) {
+      const uint32_t nch = (total + (uint32_t)CE - 1u) / (uint32_t)CE;
+      const uint32_t cpp = max((nch + parts - 1u) / parts, 1u);
+      const uint32_t skip = min(part * cpp * (uint32_t)CE, total);
+      list0 += skip;
+      total = min(total - skip, cpp * (uint32_t)CE);
+    }
+  };
+  auto decode = [&](uint32_t pos) -> Item {
+    uint32_t part, parts;
+    const uint32_t item = item_at(pos, part, parts);
     Item it;
     it.n = item / I_img;
     const uint32_t ri = item - it.n * I_img, tl = ri / (uint32_t)M;
@@ -1058,12 +1090,16 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     it.lrow = it.n * (uint32_t)S + (uint32_t)uni(lv.lsi[l]);
     it.list0 = (uint32_t)uni((int)offs[item]);
     it.total = (uint32_t)uni((int)offs[item + 1u]) - it.list0;
+    it.split = parts > 1u;
+    slice(part, parts, it.list0, it.total);
     // an empty list still takes one (empty) chunk: the item has to store its zero rows anyway
     it.nchunks = max((it.total + (uint32_t)CE - 1u) / (uint32_t)CE, 1u);
     return it;
   };
   // what fetching a chunk needs to know of its item
-  auto peek = [&](uint32_t item) -> Next {
+  auto peek = [&](uint32_t pos) -> Next {
+    uint32_t part, parts;
+    const uint32_t item = item_at(pos, part, parts);
     Next nx;
     const uint32_t ri = item % I_img, tl = ri / (uint32_t)M;
     nx.m = ri - tl * (uint32_t)M;
@@ -1072,6 +1108,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     nx.l = l;
     nx.list0 = (uint32_t)uni((int)offs[item]);
     nx.total = (uint32_t)uni((int)offs[item + 1u]) - nx.list0;
+    slice(part, parts, nx.list0, nx.total);
     return nx;
   };
   // entries of chunk `c` this thread needs: its exam slot and the two rows it stages
@@ -1098,7 +1135,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   // one -- of this item or of the block's next item -- is fetched: its entry ids during phase
   // A, its sample (location, weight) and grad_output rows from phase C on.
   uint32_t pos = blockIdx.x, npos = (uint32_t)uni((int)s_pos[0]);
-  Item cur = decode(item_at(pos));
+  Item cur = decode(pos);
   uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0;
   float2 c_xy = make_float2(0.f, 0.f);
   float c_a = 0.f;
@@ -1118,7 +1155,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     if (tid == 0) fetched = gridDim.x + atomicAdd(work, 1u);
     const bool has_next = npos < total_items;
     Next nxt = {0u, 0, 0u, 0u};
-    if (has_next) nxt = peek(item_at(npos));
+    if (has_next) nxt = peek(npos);
     const int H = cur.H, W = cur.W, y0 = cur.y0, x0 = cur.x0, th = cur.th, tw = cur.tw;
     const uint32_t m = cur.m;
     const int l = cur.l;
@@ -1341,8 +1378,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       }
       MSDA_STAMP(6)
     }
-    // ---------------- the tile's grad_value rows (sole owner: plain stores) ----------------
-    {
+    // ---------------- the tile's grad_value rows ----------------
+    if (!cur.split) {                                    // sole owner: plain stores
       const int px = tid >> 1, half = tid & 1;
       const int py = px / T, pxx = px % T;
       if (py < th && pxx < tw) {
@@ -1353,11 +1390,31 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) dst[(k + px) & 3] = acc[k];
       }
+    } else if (cur.total > 0u) {
+      // One part of the tile's list: ADD to the zero-filled rows.  Float atomics run at full rate
+      // only when a wave-instruction covers whole 128-B rows, so the sums go through LDS (the
+      // value tile's space) and come back 32 lanes to a row.
+      __syncthreads();                                   // phase E of the last chunk has read the value tile
+      {
+        const int px = tid >> 1, half = tid & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_vt[px * 8 + half * 4 + ((k + px) & 3)] = acc[k];
+      }
+      __syncthreads();
+      const float *sums = reinterpret_cast<const float *>(s_vt);
+      const int c = tid & 31;
+      for (int px = tid >> 5; px < TP; px += NT / 32) {
+        const int py = px / T, pxx = px % T;
+        if (py < th && pxx < tw) {
+          const uint32_t rowi = cur.lrow + (uint32_t)((y0 + py) * W + x0 + pxx);
+          atomicAdd(grad_value + (size_t)(rowi * (uint32_t)M + m) * 32u + (size_t)c, sums[px * 32 + c]);
+        }
+      }
     }
     if (!has_next) break;
     pos = npos;
     npos = (uint32_t)uni((int)s_pos[(k + 1u) & 1u]);
-    cur = decode(item_at(pos));
+    cur = decode(pos);
   }
   MSDA_STAMP_FLUSH
 }
@@ -1693,9 +1750,19 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
                      0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
                      entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
+  // Small batches: fewer than ~8 tiles per workgroup means the kernel runs as long as its longest
+  // list (coarse-level tiles), so those lists are split over workgroups that add their partial
+  // sums with float atomics into a zero-filled grad_value.
+  const size_t est_items = (size_t)N * M * (size_t)((S + binned::TP - 1) / binned::TP);
+  const int split_enable = est_items < (size_t)16 * cus ? 1 : 0;
+  if (split_enable) {
+    const hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * 32, st);
+    if (e != hipSuccess)
+      return fail(MSDA_ERR_LAUNCH, "%s: hipMemsetAsync(grad_value) failed: %s", who, hipGetErrorString(e));
+  }
   hipLaunchKernelGGL(binned::msda_bwd_binned_kernel<VT>, dim3(2 * cus), dim3(binned::NT), 0, st,
                      grad_out, value, shapes, lsi, loc, aw, offs, entries, work, key_cap, N, S, M, L,
-                     P, grad_value, grad_loc, grad_aw);
+                     P, split_enable, grad_value, grad_loc, grad_aw);
   return check_launch(who);
 }
 
