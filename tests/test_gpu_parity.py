@@ -597,3 +597,37 @@ def test_module_fused_prologue_matches_default(msda):
     assert rel_err(outs[1], outs[0]) < FWD_TOL_F32
     for k in grads[0]:
         assert rel_err(grads[1][k], grads[0][k]) < GRAD_TOL_F32, k
+
+
+def test_forward_backward_capture_into_a_hip_graph(msda):
+    """The boundary enqueues on torch's current stream and never synchronises or allocates behind
+    torch's back (the backward's workspace comes from torch's allocator), so a step can be captured
+    into a HIP graph and replayed on new data in the same buffers."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(2, synthetic.encoder_shapes(256), dist="model", seed=3, device="cuda")
+    a = [inp[k] for k in ("value", "spatial_shapes", "level_start_index", "sampling_locations",
+                          "attention_weights")]
+    go = inp["grad_output"]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # warm-up outside the capture
+        msda.ms_deform_attn_forward(*a, 128)
+        msda.ms_deform_attn_backward(*a, go, 128)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = msda.ms_deform_attn_forward(*a, 128)
+        gv, gl, ga = msda.ms_deform_attn_backward(*a, go, 128)
+    # new data in the captured input buffers, then replay
+    fresh = synthetic.make_inputs(2, synthetic.encoder_shapes(256), dist="model", seed=4, device="cuda")
+    for k, t in zip(("value", "sampling_locations", "attention_weights"), (a[0], a[3], a[4])):
+        t.copy_(fresh[k])
+    go.copy_(fresh["grad_output"])
+    graph.replay()
+    torch.cuda.synchronize()
+    ref_out = msda.ms_deform_attn_forward(*a, 128)
+    ref_gv, ref_gl, ref_ga = msda.ms_deform_attn_backward(*a, go, 128)
+    n = lambda t: t.cpu().numpy()
+    assert rel_err(n(out), n(ref_out)) < 1e-6
+    for x, y in ((gv, ref_gv), (gl, ref_gl), (ga, ref_ga)):
+        assert rel_err(n(x), n(y)) < ORDER_TOL
