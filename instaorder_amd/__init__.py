@@ -6,6 +6,7 @@ hot path of SNU-VGILab/InstaOrder (Mask2Former's MSDeformAttnPixelDecoder encode
   functions.py        MSDeformAttnFunction (autograd wrapper) + the CPU-tensor PyTorch path
   modules.py          MSDeformAttn (the nn.Module that calls the op)
   encoder.py          the pixel decoder's MSDA encoder stack, detectron2-free
+  pixel_decoder.py    MSDeformAttnPixelDecoder around it (input projections, FPN, mask features)
   synthetic.py        synthetic inputs of the encoder's shape (bench, tests)
 """
 from .functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch

@@ -631,3 +631,25 @@ def test_forward_backward_capture_into_a_hip_graph(msda):
     assert rel_err(n(out), n(ref_out)) < 1e-6
     for x, y in ((gv, ref_gv), (gl, ref_gl), (ga, ref_ga)):
         assert rel_err(n(x), n(y)) < ORDER_TOL
+
+
+def test_pixel_decoder_mirror_gpu_matches_cpu_path(msda):
+    """Row f4: the detectron2-free pixel decoder on the GPU (HIP kernels inside its encoder) against
+    the same module on the CPU (PyTorch grid_sample path)."""
+    from instaorder_amd import ext
+    from instaorder_amd.pixel_decoder import MSDeformAttnPixelDecoder
+    torch.manual_seed(1)
+    shape = {"res2": (96, 4), "res3": (192, 8), "res4": (384, 16), "res5": (768, 32)}
+    pd = MSDeformAttnPixelDecoder(shape, transformer_enc_layers=2)
+    feats = {k: torch.randn(2, c, 128 // s, 160 // s) for k, (c, s) in shape.items()}
+    ref_mask, ref_low, ref_multi = pd.forward_features(feats)
+    before = ext.launch_count()
+    pd_gpu = pd.cuda()
+    out_mask, out_low, out_multi = pd_gpu.forward_features({k: v.cuda() for k, v in feats.items()})
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 2, "the encoder did not take the HIP kernels"
+    n = lambda t: t.detach().cpu().numpy()
+    assert rel_err(n(out_mask), n(ref_mask)) < 1e-4
+    assert rel_err(n(out_low), n(ref_low)) < 1e-4
+    for a, b in zip(out_multi, ref_multi):
+        assert rel_err(n(a), n(b)) < 1e-4

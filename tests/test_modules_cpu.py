@@ -111,3 +111,29 @@ def test_config_c1_cpu_forward_512():
     ref_pts = synthetic.reference_points(shapes)[None, :, None, :].expand(1, s, 3, 2)
     y = mod(x, ref_pts, x, inp["spatial_shapes"], inp["level_start_index"])
     assert tuple(y.shape) == (1, s, 256) and torch.isfinite(y).all()
+
+
+def test_pixel_decoder_mirror_shapes_and_state_dict_keys():
+    """Row f4: the detectron2-free MSDeformAttnPixelDecoder (reference msdeformattn.py:257-487):
+    output shapes of forward_features, the reference's sub-module names, gradients reach the
+    input projections through the encoder."""
+    import torch
+    from instaorder_amd.pixel_decoder import MSDeformAttnPixelDecoder
+    torch.manual_seed(0)
+    shape = {"res2": (96, 4), "res3": (192, 8), "res4": (384, 16), "res5": (768, 32)}
+    pd = MSDeformAttnPixelDecoder(shape, transformer_enc_layers=2, use_adapters=True)
+    keys = set(pd.state_dict().keys())
+    for k in ("input_proj.0.0.weight", "input_proj.2.1.bias", "mask_features.weight", "mask_features.bias",
+              "adapter_1.weight", "adapter_1.norm.weight", "layer_1.weight", "layer_1.norm.bias",
+              "transformer.level_embed", "transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
+              "transformer.encoder.layers.1.self_attn.value_proj.bias"):
+        assert k in keys, k
+    assert "adapter_1.bias" not in keys                    # norm == "GN": convs without bias
+    feats = {k: torch.randn(2, c, 96 // s, 128 // s) for k, (c, s) in shape.items()}
+    mask_features, enc_low, multi = pd.forward_features(feats)
+    assert mask_features.shape == (2, 256, 24, 32)         # stride 4
+    assert enc_low.shape == (2, 256, 3, 4)                 # stride 32
+    assert [tuple(m.shape[-2:]) for m in multi] == [(3, 4), (6, 8), (12, 16)]
+    (mask_features.square().mean() + multi[2].mean()).backward()
+    assert pd.input_proj[0][0].weight.grad is not None and pd.input_proj[0][0].weight.grad.abs().sum() > 0
+    assert pd.adapter_1.weight.grad.abs().sum() > 0
