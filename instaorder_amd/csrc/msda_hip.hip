@@ -664,7 +664,10 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_zero_kernel(const int64_t *_
                                                                 int N, int M, int L, uint32_t key_cap,
                                                                 uint32_t *__restrict__ counts) {
   const uint64_t nkeys = count_lists(shapes, N, M, L);
-  if (blockIdx.x == 0 && threadIdx.x == 0) counts[(size_t)key_cap + 1] = 0u;   // the tile kernel's work counter
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    counts[(size_t)key_cap + 1] = 0u;         // the tile kernel's work counter
+    counts[2 * (size_t)key_cap + 3] = 0u;     // the pad word behind the list starts: the tile kernel's zero word
+  }
   if (nkeys > key_cap) return;
   for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k <= nkeys; k += (uint64_t)gridDim.x * 256u)
     counts[k] = 0u;
@@ -984,7 +987,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ loc, const float *__restrict__ aw,
     const uint32_t *__restrict__ offs, const uint32_t *__restrict__ entries,
-    uint32_t *__restrict__ work, uint32_t key_cap, int N, int S, int M, int L, int P, int split_enable,
+    const uint32_t *__restrict__ zero_word, uint32_t *__restrict__ work, uint32_t key_cap, int N, int S,
+    int M, int L, int P, int split_enable,
     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw) {
   __shared__ float4 s_vt[(ZROW + 1) * 8];   // value tile rows (8 x 16 B each)
   __shared__ float4 s_go[(CE + 1) * 8];     // grad_output rows of this chunk's entries + a zero row
@@ -1111,24 +1115,30 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     slice(part, parts, nx.list0, nx.total);
     return nx;
   };
-  // entries of chunk `c` this thread needs: its exam slot and the two rows it stages
+  // entries of chunk `c` this thread needs: its exam slot and the two rows it stages.
+  // All prefetch loads are UNCONDITIONAL (lanes with nothing to fetch read element 0 and drop it):
+  // loads inside exec-masked blocks make the compiler fall back to s_waitcnt vmcnt(0) at the first
+  // use, which would expose the latency of the newest requests as well.
   auto load_ids = [&](const Next &it, uint32_t c, uint32_t &ent, uint32_t &r0, uint32_t &r1) {
     const uint32_t e = c * (uint32_t)CE + slot, e0 = c * (uint32_t)CE + gslot, e1 = e0 + 64u;
-    ent = e < it.total ? entries[it.list0 + e] : 0u;       // mask 0: nothing to examine
-    r0 = e0 < it.total ? entries[it.list0 + e0] : 0u;
-    r1 = e1 < it.total ? entries[it.list0 + e1] : 0u;
+    // past the end of the list: the workspace's zero word (mask 0: nothing to examine), so the
+    // loaded value needs no fix-up -- nothing touches it before its use, a full phase later
+    ent = *(e < it.total ? entries + it.list0 + e : zero_word);
+    r0 = *(e0 < it.total ? entries + it.list0 + e0 : zero_word);
+    r1 = *(e1 < it.total ? entries + it.list0 + e1 : zero_word);
   };
   auto load_sample = [&](const Next &it, uint32_t ent, float2 &xy, float &a) {
-    if ((ent >> p) & 1u) {
-      const uint32_t s = (((ent >> 4) * (uint32_t)M + it.m) * (uint32_t)L + (uint32_t)it.l) * (uint32_t)P + p;
-      xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
-      a = aw[s];
-    }
+    const bool live = (ent >> p) & 1u;
+    const uint32_t s = live ? (((ent >> 4) * (uint32_t)M + it.m) * (uint32_t)L + (uint32_t)it.l) * (uint32_t)P + p : 0u;
+    xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
+    a = aw[s];
   };
   auto load_rows = [&](const Next &it, uint32_t c, uint32_t r0, uint32_t r1, float4 &g0, float4 &g1) {
     const uint32_t e0 = c * (uint32_t)CE + gslot;
-    if (e0 < it.total) g0 = ldrow4(grad_out, ((r0 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u);
-    if (e0 + 64u < it.total) g1 = ldrow4(grad_out, ((r1 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u);
+    const uint32_t o0 = e0 < it.total ? ((r0 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u : gsub * 16u;
+    const uint32_t o1 = e0 + 64u < it.total ? ((r1 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u : gsub * 16u;
+    g0 = ldrow4(grad_out, o0);
+    g1 = ldrow4(grad_out, o1);
   };
 
   // The block's items and their chunks form one stream.  While a chunk is processed the next
@@ -1761,8 +1771,8 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
       return fail(MSDA_ERR_LAUNCH, "%s: hipMemsetAsync(grad_value) failed: %s", who, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(binned::msda_bwd_binned_kernel<VT>, dim3(2 * cus), dim3(binned::NT), 0, st,
-                     grad_out, value, shapes, lsi, loc, aw, offs, entries, work, key_cap, N, S, M, L,
-                     P, split_enable, grad_value, grad_loc, grad_aw);
+                     grad_out, value, shapes, lsi, loc, aw, offs, entries, offs + (size_t)key_cap + 1, work,
+                     key_cap, N, S, M, L, P, split_enable, grad_value, grad_loc, grad_aw);
   return check_launch(who);
 }
 
