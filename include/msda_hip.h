@@ -73,7 +73,7 @@ int msda_forward_f64(const double *value, const int64_t *spatial_shapes,
  * grad_value needs no zero-fill by the caller (the reference's caller does at::zeros_like,
  * ms_deform_attn_cuda.cu:126); grad_sampling_loc and grad_attn_weight are fully written.
  *
- * channels == 32, num_point <= 8, num_levels <= 8 (every InstaFormer configuration) runs the
+ * channels == 32, num_point <= 4, num_levels <= 8 (every InstaFormer configuration) runs the
  * binned destination-tiled kernels, which sort the samples by destination tile in a workspace
  * of msda_backward_workspace_bytes(...) bytes; other shapes run the generic atomic kernels and
  * need none.  The *_ws variants take the workspace from the caller (any device memory, 4-byte
@@ -111,7 +111,7 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
  * pixel_decoder/msdeformattn.py:435-441).  value / output / grad_output are bfloat16 bit
  * patterns (uint16_t); sampling locations, attention weights and ALL THREE gradients are fp32;
  * accumulation is fp32.  grad_value comes back in fp32 (algorithmic bytes 68.00 B/sample, not
- * 62.67).  Both need channels == 32 (backward also num_point <= 8, num_levels <= 8).  Same
+ * 62.67).  Both need channels == 32 (backward also num_point <= 4, num_levels <= 8).  Same
  * kernels as the fp32 fast paths; msda_backward_bf16_ws as msda_backward_f32_ws.
  */
 int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
 //   msda_bwd_binned_kernel      the tile kernel; workgroups take items from a queue ordered
 //                               coarse level first (their tiles carry the longest lists).
 // Workspace (caller-provided), uint32 words: counters[key_cap + 1], work counter,
-// starts[key_cap + 1], pad, descriptors[quads], entries[16 * quads]; key_cap = N*M*S >= number
+// starts[key_cap + 1], a zero word (what prefetches past the end of a list read), descriptors[quads], entries[16 * quads]; key_cap = N*M*S >= number
 // of lists (a level has at most H*W tiles), and a quad touches at most 16 tiles (typically
 // 1-2: the bound is address space, not traffic).
 // =======================================================================================
