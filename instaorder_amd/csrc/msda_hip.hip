@@ -935,17 +935,15 @@ __global__ __launch_bounds__(1024) void msda_bwd_bin_scan_kernel(const int64_t *
   if (nk64 > key_cap) return;
   const uint32_t nkeys = (uint32_t)nk64;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  // tiles of 1024 consecutive keys (coalesced), carried sequentially
+  // tiles of 4096 consecutive keys (4 per thread), carried sequentially
   uint32_t carry = 0;
-  for (uint32_t k0 = 0; k0 < nkeys; k0 += 1024u) {
-    const uint32_t k = k0 + tid;
-    const uint32_t c = k < nkeys ? counts[k] : 0u;
-    uint32_t inc = c;
+  for (uint32_t k0 = 0; k0 < nkeys; k0 += 4096u) {
+    const uint32_t k = k0 + 4u * tid;
+    uint32_t c[4];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d);
-      if ((int)lane >= d) inc += o;
-    }
+    for (uint32_t i = 0; i < 4u; ++i) c[i] = k + i < nkeys ? counts[k + i] : 0u;
+    const uint32_t sum = c[0] + c[1] + c[2] + c[3];
+    const uint32_t inc = wave_inclusive_scan(sum);
     if (lane == 63u) s_wave[wave] = inc;
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
@@ -954,10 +952,14 @@ __global__ __launch_bounds__(1024) void msda_bwd_bin_scan_kernel(const int64_t *
       if (w < wave) wbase += v;
       tot += v;
     }
-    const uint32_t ex = carry + wbase + inc - c;
-    if (k < nkeys) {
-      offs[k] = ex;
-      counts[k] = ex;
+    uint32_t ex = carry + wbase + inc - sum;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {
+      if (k + i < nkeys) {
+        offs[k + i] = ex;
+        counts[k + i] = ex;
+      }
+      ex += c[i];
     }
     carry += tot;
     __syncthreads();
