@@ -151,6 +151,20 @@ __device__ __forceinline__ void strow4(bf16_t *__restrict__ base, uint32_t f32_o
   *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(base) + (f32_off >> 1)) =
       make_uint2(f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16), f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16));
 }
+// A 4-channel piece of a row as it travels in registers between its load and its store to LDS:
+// fp32 as it is, bf16 still packed (half the registers), widened only at the store.
+template <typename ST> struct RawPiece;
+template <> struct RawPiece<float> { typedef float4 type; };
+template <> struct RawPiece<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 ld_raw_piece(const float *__restrict__ base, uint32_t f32_off) { return ld16(base, f32_off); }
+__device__ __forceinline__ uint2 ld_raw_piece(const bf16_t *__restrict__ base, uint32_t f32_off) {
+  return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + (f32_off >> 1));
+}
+__device__ __forceinline__ float4 widen_piece(float4 v) { return v; }
+__device__ __forceinline__ float4 widen_piece(uint2 r) {
+  return make_float4(bf16_to_f32(r.x & 0xffffu), bf16_to_f32(r.x >> 16), bf16_to_f32(r.y & 0xffffu),
+                     bf16_to_f32(r.y >> 16));
+}
 // NS samples of one level: all 4*NS corner rows are requested before the first is used.
 template <typename VT, int NS>
 __device__ __forceinline__ void fwd_samples_d32(const VT *__restrict__ value, uint32_t lbyte,
@@ -1135,12 +1149,13 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
     xy = *reinterpret_cast<const float2 *>(loc + 2u * s);
     a = aw[s];
   };
-  auto load_rows = [&](const Next &it, uint32_t c, uint32_t r0, uint32_t r1, float4 &g0, float4 &g1) {
+  typedef typename RawPiece<ST>::type Raw;
+  auto load_rows = [&](const Next &it, uint32_t c, uint32_t r0, uint32_t r1, Raw &g0, Raw &g1) {
     const uint32_t e0 = c * (uint32_t)CE + gslot;
     const uint32_t o0 = e0 < it.total ? ((r0 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u : gsub * 16u;
     const uint32_t o1 = e0 + 64u < it.total ? ((r1 >> 4) * (uint32_t)M + it.m) * 128u + gsub * 16u : gsub * 16u;
-    g0 = ldrow4(grad_out, o0);
-    g1 = ldrow4(grad_out, o1);
+    g0 = ld_raw_piece(grad_out, o0);
+    g1 = ld_raw_piece(grad_out, o1);
   };
 
   // The block's items and their chunks form one stream.  While a chunk is processed the next
@@ -1151,7 +1166,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
   uint32_t c_ent = 0, n_ent = 0, n_r0 = 0, n_r1 = 0;
   float2 c_xy = make_float2(0.f, 0.f);
   float c_a = 0.f;
-  float4 c_g0 = make_float4(0.f, 0.f, 0.f, 0.f), c_g1 = c_g0;
+  Raw c_g0 = Raw(), c_g1 = Raw();
   {
     const Next first = {cur.m, cur.l, cur.list0, cur.total};
     uint32_t r0 = 0, r1 = 0;
@@ -1223,8 +1238,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_binned_kernel(
       __syncthreads();   // every wave is past phases D/E of the previous chunk
       MSDA_STAMP(2)
       // ---------------- phase C: contributions -> pixel buckets; rows, home list -> LDS ----------------
-      s_go[gslot * 8u + gsub] = c_g0;
-      s_go[(gslot + 64u) * 8u + gsub] = c_g1;
+      s_go[gslot * 8u + gsub] = widen_piece(c_g0);
+      s_go[(gslot + 64u) * 8u + gsub] = widen_piece(c_g1);
       if (p == 0u) s_q[slot] = c_ent >> 4;
       if (chunk == 0) {
         // The item's value tile (zeros outside the level).  fp32 rows go global -> LDS directly
