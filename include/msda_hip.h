@@ -167,6 +167,23 @@ int msda_fused_backward_f32(const float *value, const int64_t *spatial_shapes,
                             float *grad_value, float *grad_sampling_offsets, float *grad_attn_logits,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* bf16 twins of the fused boundary: value / output / grad_output bfloat16 bit patterns, everything
+ * else (offsets, logits, reference points, all three gradients) fp32 -- as msda_forward_bf16 /
+ * msda_backward_bf16.  Same workspace query. */
+int msda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const float *reference_points,
+                            const float *sampling_offsets, const float *attn_logits, int batch,
+                            int spatial_size, int num_heads, int channels, int num_levels,
+                            int num_query, int num_point, uint16_t *output, void *stream);
+
+int msda_fused_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                             const int64_t *level_start_index, const float *reference_points,
+                             const float *sampling_offsets, const float *attn_logits,
+                             const uint16_t *grad_output, int batch, int spatial_size, int num_heads,
+                             int channels, int num_levels, int num_query, int num_point,
+                             float *grad_value, float *grad_sampling_offsets, float *grad_attn_logits,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

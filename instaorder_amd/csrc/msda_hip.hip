@@ -1870,10 +1870,10 @@ int backward_bf16(const char *who, const uint16_t *value, const int64_t *shapes,
 // ---- row f3: fused boundary (fp32) ----
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-int fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *refp,
-                      const float *off, const float *logits, int N, int S, int M, int D, int L, int Lq,
-                      int P, float *out, void *stream) {
-  const char *who = "msda_fused_forward_f32";
+template <typename VT>
+int fused_forward(const char *who, const VT *value, const int64_t *shapes, const int64_t *lsi, const float *refp,
+                  const float *off, const float *logits, int N, int S, int M, int D, int L, int Lq,
+                  int P, VT *out, void *stream) {
   if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
   if ((size_t)N * Lq == 0) return MSDA_OK;
   const size_t npairs = (size_t)N * Lq * M, limit = (size_t)1 << 30;
@@ -1883,11 +1883,11 @@ int fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "%s: needs channels == 32, num_levels * num_point <= %d, aligned tensors of < 2^30 "
                 "elements (use the unfused entry points otherwise)", who, FWD_FUSED_MAX_LP);
-  constexpr uint32_t GP = 64u / FwdLanes<float>::LPG;
+  constexpr uint32_t GP = 64u / FwdLanes<VT>::LPG;
   const size_t lds = (size_t)4 * ((size_t)2 * GP * (size_t)(L * P + 1) * 16 + (((size_t)GP * L * P + 3) / 4) * 16);
   const uint32_t nq = (uint32_t)((size_t)N * Lq), nunits = ((nq + GP - 1u) / GP) * (uint32_t)M;
   const uint32_t nblk = (nunits + 3u) / 4u;
-  hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<float, true>), dim3(nblk), dim3(256), lds,
+  hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT, true>), dim3(nblk), dim3(256), lds,
                      static_cast<hipStream_t>(stream), value, shapes, lsi, off, logits, refp, S, M, L, Lq, P,
                      nq, nunits, nblk, false, out);
   return check_launch(who);
@@ -1901,11 +1901,11 @@ size_t fused_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq,
   return align256(samples * 8) + align256(samples * 4) + align256(inner);
 }
 
-int fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *refp,
-                       const float *off, const float *logits, const float *grad_out, int N, int S, int M,
+// `value` / `grad_out` are fp32 or (bf16 == true) bfloat16 bit patterns
+int fused_backward(const char *who, bool bf16, const void *value, const int64_t *shapes, const int64_t *lsi, const float *refp,
+                       const float *off, const float *logits, const void *grad_out, int N, int S, int M,
                        int D, int L, int Lq, int P, float *grad_value, float *grad_off, float *grad_logits,
                        void *workspace, size_t workspace_bytes, void *stream) {
-  const char *who = "msda_fused_backward_f32";
   if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
   const size_t need = fused_backward_workspace_bytes(N, S, M, D, L, Lq, P);
   if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255u))
@@ -1927,9 +1927,13 @@ int fused_backward_f32(const float *value, const int64_t *shapes, const int64_t 
                        logits, M, L, P, npairs, loc, aw);
     if (int rc = check_launch(who)) return rc;
   }
-  if (int rc = backward_f32(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P, grad_value,
-                            grad_off, grad_logits, inner, inner_bytes, false, stream))
-    return rc;
+  const int rc = bf16 ? backward_bf16(who, static_cast<const uint16_t *>(value), shapes, lsi, loc, aw,
+                                      static_cast<const uint16_t *>(grad_out), N, S, M, D, L, Lq, P, grad_value,
+                                      grad_off, grad_logits, inner, inner_bytes, false, stream)
+                      : backward_f32(who, static_cast<const float *>(value), shapes, lsi, loc, aw,
+                                     static_cast<const float *>(grad_out), N, S, M, D, L, Lq, P, grad_value,
+                                     grad_off, grad_logits, inner, inner_bytes, false, stream);
+  if (rc) return rc;
   if (npairs) {
     hipLaunchKernelGGL(msda_fused_epilogue_kernel, dim3((unsigned)nblk), dim3(256), 0, st, shapes, aw, L, P,
                        npairs, grad_off, grad_logits);
@@ -1947,9 +1951,33 @@ int msda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
                            const float *sampling_offsets, const float *attn_logits, int batch,
                            int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                            int num_point, float *output, void *stream) {
-  return fused_forward_f32(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                           attn_logits, batch, spatial_size, num_heads, channels, num_levels, num_query,
-                           num_point, output, stream);
+  return fused_forward<float>("msda_fused_forward_f32", value, spatial_shapes, level_start_index,
+                              reference_points, sampling_offsets, attn_logits, batch, spatial_size, num_heads,
+                              channels, num_levels, num_query, num_point, output, stream);
+}
+
+int msda_fused_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const float *reference_points,
+                            const float *sampling_offsets, const float *attn_logits, int batch,
+                            int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                            int num_point, uint16_t *output, void *stream) {
+  return fused_forward<bf16_t>("msda_fused_forward_bf16", reinterpret_cast<const bf16_t *>(value),
+                               spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                               attn_logits, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                               num_point, reinterpret_cast<bf16_t *>(output), stream);
+}
+
+int msda_fused_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                             const int64_t *level_start_index, const float *reference_points,
+                             const float *sampling_offsets, const float *attn_logits,
+                             const uint16_t *grad_output, int batch, int spatial_size, int num_heads,
+                             int channels, int num_levels, int num_query, int num_point, float *grad_value,
+                             float *grad_sampling_offsets, float *grad_attn_logits, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+  return fused_backward("msda_fused_backward_bf16", true, value, spatial_shapes, level_start_index,
+                        reference_points, sampling_offsets, attn_logits, grad_output, batch, spatial_size,
+                        num_heads, channels, num_levels, num_query, num_point, grad_value,
+                        grad_sampling_offsets, grad_attn_logits, workspace, workspace_bytes, stream);
 }
 
 size_t msda_fused_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
@@ -1965,10 +1993,10 @@ int msda_fused_backward_f32(const float *value, const int64_t *spatial_shapes,
                             int channels, int num_levels, int num_query, int num_point, float *grad_value,
                             float *grad_sampling_offsets, float *grad_attn_logits, void *workspace,
                             size_t workspace_bytes, void *stream) {
-  return fused_backward_f32(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                            attn_logits, grad_output, batch, spatial_size, num_heads, channels, num_levels,
-                            num_query, num_point, grad_value, grad_sampling_offsets, grad_attn_logits,
-                            workspace, workspace_bytes, stream);
+  return fused_backward("msda_fused_backward_f32", false, value, spatial_shapes, level_start_index,
+                        reference_points, sampling_offsets, attn_logits, grad_output, batch, spatial_size,
+                        num_heads, channels, num_levels, num_query, num_point, grad_value,
+                        grad_sampling_offsets, grad_attn_logits, workspace, workspace_bytes, stream);
 }
 
 #ifdef MSDA_PHASE_STAMPS

@@ -51,9 +51,11 @@ def _load():
     lib.msda_last_error.restype = ctypes.c_char_p
     lib.msda_launch_count.restype = ctypes.c_uint64
     lib.msda_abi_version.restype = _I
-    lib.msda_fused_forward_f32.argtypes, lib.msda_fused_forward_f32.restype = [_P] * 6 + [_I] * 7 + [_P, _P], _I
-    lib.msda_fused_backward_f32.argtypes = [_P] * 7 + [_I] * 7 + [_P] * 4 + [ctypes.c_size_t, _P]
-    lib.msda_fused_backward_f32.restype = _I
+    for suffix in ("f32", "bf16"):
+        f = getattr(lib, "msda_fused_forward_" + suffix)
+        f.argtypes, f.restype = [_P] * 6 + [_I] * 7 + [_P, _P], _I
+        b = getattr(lib, "msda_fused_backward_" + suffix)
+        b.argtypes, b.restype = [_P] * 7 + [_I] * 7 + [_P] * 4 + [ctypes.c_size_t, _P], _I
     lib.msda_fused_backward_workspace_bytes.argtypes = [_I] * 7
     lib.msda_fused_backward_workspace_bytes.restype = ctypes.c_size_t
     if lib.msda_abi_version() != 3:
@@ -181,7 +183,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
 # ---------------------------------------------------------------------------------------------
 def fused_forward_supported(value, reference_points, num_levels, num_point):
     """True when msda_fused_forward_f32 takes the call (else use the unfused functions)."""
-    return (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.shape[3] == 32
+    return (value.is_cuda and value.dtype in (torch.float32, torch.bfloat16) and value.dim() == 4
+            and value.shape[3] == 32
             and reference_points.shape[-1] == 2 and num_levels * num_point <= 16)
 
 
@@ -193,8 +196,10 @@ def _fused_common(value, spatial_shapes, level_start_index, reference_points, sa
              ("level_start_index", level_start_index), ("reference_points", reference_points),
              ("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits))
     _check_inputs(named)
-    if any(t.dtype != torch.float32 for t in (value, reference_points, sampling_offsets, attn_logits)):
-        raise RuntimeError("the fused MSDA entry points are fp32 only")
+    if value.dtype not in (torch.float32, torch.bfloat16) or any(
+            t.dtype != torch.float32 for t in (reference_points, sampling_offsets, attn_logits)):
+        raise RuntimeError("the fused MSDA entry points take an fp32 or bf16 value and fp32 reference "
+                           "points, offsets and logits")
     if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
         raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
     if value.dim() != 4 or sampling_offsets.dim() != 6:
@@ -219,7 +224,7 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, refer
     lib = _load()
     with torch.cuda.device(value.device):
         output = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
-        rc = lib.msda_fused_forward_f32(
+        rc = getattr(lib, "msda_fused_forward_" + _SUFFIX[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             reference_points.data_ptr(), sampling_offsets.data_ptr(), attn_logits.data_ptr(),
             n, s, m, d, nl, lq, npt, output.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -238,12 +243,12 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, refe
     _check_inputs((("grad_output", grad_output),))
     lib = _load()
     with torch.cuda.device(value.device):
-        grad_value = torch.empty_like(value)
+        grad_value = torch.empty(value.shape, dtype=torch.float32, device=value.device)   # fp32 also for bf16
         grad_offsets = torch.empty_like(sampling_offsets)
         grad_logits = torch.empty_like(attn_logits)
         nbytes = int(lib.msda_fused_backward_workspace_bytes(n, s, m, d, nl, lq, npt))
         workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=value.device)
-        rc = lib.msda_fused_backward_f32(
+        rc = getattr(lib, "msda_fused_backward_" + _SUFFIX[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             reference_points.data_ptr(), sampling_offsets.data_ptr(), attn_logits.data_ptr(),
             grad_output.data_ptr(), n, s, m, d, nl, lq, npt, grad_value.data_ptr(),

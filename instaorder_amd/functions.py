@@ -69,7 +69,7 @@ class MSDeformAttnFusedFunction(Function):
             # d loc / d ref = 1 and grad_offsets = grad_loc / (W_l, H_l)
             wh = shapes.flip(-1).to(grad_offsets.dtype)                       # (W_l, H_l)
             grad_ref = (grad_offsets * wh[None, None, None, :, None, :]).sum(dim=(2, 4))
-        return grad_value, None, None, grad_ref, grad_offsets, grad_logits
+        return grad_value.to(value.dtype), None, None, grad_ref, grad_offsets, grad_logits
 
 
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):

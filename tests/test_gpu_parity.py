@@ -653,3 +653,34 @@ def test_pixel_decoder_mirror_gpu_matches_cpu_path(msda):
     assert rel_err(n(out_low), n(ref_low)) < 1e-4
     for a, b in zip(out_multi, ref_multi):
         assert rel_err(n(a), n(b)) < 1e-4
+
+
+def test_fused_entry_points_bf16_match_unfused(msda):
+    """bf16 twins of the fused boundary against the unfused bf16 entry points fed by the same
+    prologue arithmetic in PyTorch (identical locations; weights to fp32 rounding)."""
+    from instaorder_amd import ext
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    inp, ref, off, logits = _fused_inputs(2, shapes, 8, 4, None, seed=12)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    ss, lsi = dev["spatial_shapes"], dev["level_start_index"]
+    v16, go16 = dev["value"].bfloat16(), dev["grad_output"].bfloat16()
+    ref, off, logits = ref.cuda(), off.cuda(), logits.cuda()
+    n, lq, m, nl, p, _ = off.shape
+    aw = torch.softmax(logits, -1).view(n, lq, m, nl, p)
+    normalizer = torch.stack([ss[..., 1], ss[..., 0]], -1)
+    loc = (ref[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]).contiguous()
+    o_ref = msda.ms_deform_attn_forward(v16, ss, lsi, loc, aw, 128)
+    gv_ref, gl_ref, ga_ref = msda.ms_deform_attn_backward(v16, ss, lsi, loc, aw, go16, 128)
+    # chain rule of the prologue, in PyTorch
+    goff_ref = gl_ref / normalizer[None, None, None, :, None, :]
+    ga2 = ga_ref.view(n, lq, m, nl * p)
+    aw2 = aw.view(n, lq, m, nl * p)
+    glog_ref = aw2 * (ga2 - (aw2 * ga2).sum(-1, keepdim=True))
+    out = ext.ms_deform_attn_fused_forward(v16, ss, lsi, ref, off, logits)
+    gv, goff, glog = ext.ms_deform_attn_fused_backward(v16, ss, lsi, ref, off, logits, go16)
+    assert out.dtype == torch.bfloat16 and gv.dtype == torch.float32
+    c = lambda t: t.float().cpu().numpy()
+    assert rel_err(c(out), c(o_ref)) < BF16_TOL
+    assert rel_err(c(gv), c(gv_ref)) < GRAD_TOL_F32
+    assert rel_err(c(goff), c(goff_ref)) < GRAD_TOL_F32
+    assert rel_err(c(glog), c(glog_ref)) < GRAD_TOL_F32
