@@ -85,11 +85,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one GPU per rank; MSDA_BENCH_BACKEND=gloo lets several ranks rehearse the launch on ONE GPU
+    # (RCCL refuses two ranks on a device) -- a rehearsal of the control path, not a measurement
+    backend = os.environ.get("MSDA_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     import MultiScaleDeformableAttention as MSDA
     from instaorder_amd import distributed as D
     from instaorder_amd import ext, synthetic
-    D.init("nccl")            # no-op for one rank; RCCL process group otherwise
+    D.init(backend)           # no-op for one rank; RCCL process group otherwise
     dist_on = world > 1
 
     batch, image = WORKLOADS[args.workload]
