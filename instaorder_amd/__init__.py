@@ -1,7 +1,7 @@
 """instaorder_amd -- MI355X-native multi-scale deformable attention (MSDA), the one native
 hot path of SNU-VGILab/InstaOrder (Mask2Former's MSDeformAttnPixelDecoder encoder).
 
-  csrc/msda_hip.hip   hand-written HIP kernels (gfx950) + the C ABI (include/msda_hip.h)
+  csrc/msda_hip.hip   host side + the C ABI (include/msda_hip.h); kernels in csrc/msda_*.inc (gfx950 HIP)
   ext.py              host side of the extension boundary (checks, allocation, stream)
   functions.py        MSDeformAttnFunction (autograd wrapper) + the CPU-tensor PyTorch path
   modules.py          MSDeformAttn (the nn.Module that calls the op)

@@ -20,7 +20,8 @@ def find_hipcc():
 
 
 def build(force=False, verbose=False):
-    deps = [SRC, os.path.join(ROOT, "include", "msda_hip.h")]
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, "include", "msda_hip.h")]
     if (not force and os.path.exists(LIB)
             and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)):
         return LIB
