@@ -684,3 +684,40 @@ def test_fused_entry_points_bf16_match_unfused(msda):
     assert rel_err(c(gv), c(gv_ref)) < GRAD_TOL_F32
     assert rel_err(c(goff), c(goff_ref)) < GRAD_TOL_F32
     assert rel_err(c(glog), c(glog_ref)) < GRAD_TOL_F32
+
+
+@pytest.mark.parametrize("batch,fast", [(3, True), (4, False)])
+def test_multi_gib_value_tensor_vs_oracle(msda, oracle, batch, fast):
+    """Maximum sizes: a value tensor of 3.2 GB stays on the D == 32 kernels, whose 32-bit byte
+    offsets then pass 2^31; one of 4.3 GB is over their 4-GiB limit and takes the 64-bit generic
+    kernels.  Few queries, uniform locations (every part of the tensor is sampled); against the
+    fp32 C oracle."""
+    from instaorder_amd import ext
+    shapes = [(1024, 1024), (32, 32)]
+    s, m, d, p, lq = 1024 * 1024 + 32 * 32, 8, 32, 4, 4096
+    g = torch.Generator(device="cuda").manual_seed(7)
+    value = torch.randn((batch, s, m, d), generator=g, device="cuda")
+    loc = torch.rand((batch, lq, m, 2, p, 2), generator=g, device="cuda")
+    aw = torch.softmax(torch.randn((batch, lq, m, 2 * p), generator=g, device="cuda"), -1).view(batch, lq, m, 2, p)
+    go = torch.randn((batch, lq, m * d), generator=g, device="cuda")
+    ss = torch.tensor(shapes, dtype=torch.int64, device="cuda")
+    lsi = torch.tensor([0, 1024 * 1024], dtype=torch.int64, device="cuda")
+    ws = int(ext._load().msda_backward_workspace_bytes(batch, s, m, d, 2, lq, p))
+    assert (ws > 0) == fast, "expected the %s kernels" % ("D == 32" if fast else "generic")
+    out = msda.ms_deform_attn_forward(value, ss, lsi, loc, aw, 1)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, ss, lsi, loc, aw, go, 1)
+    torch.cuda.synchronize()
+    n = lambda t: t.cpu().numpy()
+    v_h = n(value)
+    del value
+    o_out = oracle.forward(v_h, n(ss), n(lsi), n(loc), n(aw))
+    o_gv, o_gl, o_ga = oracle.backward(v_h, n(ss), n(lsi), n(loc), n(aw), n(go))
+    assert rel_err(n(out), o_out) < FWD_TOL_F32
+    assert rel_err(n(gl), o_gl) < GRAD_TOL_F32
+    assert rel_err(n(ga), o_ga) < GRAD_TOL_F32
+    # grad_value without fp64 copies of 4-GB arrays
+    o_gv = torch.from_numpy(o_gv)
+    gv = gv.cpu()
+    assert float((gv - o_gv).abs().max()) < GRAD_TOL_F32 * float(o_gv.abs().max())
+    # the last image is the one behind the 2^31 / 2^32 byte marks
+    assert float(o_gv[-1].abs().max()) > 0 and float(np.abs(o_out[-1]).max()) > 0
