@@ -31,6 +31,14 @@ def _cases():
     cases.append(([(16, 16)], 2, 4, 1, 4000, 1.1, 7))
     cases.append(([(20, 30), (9, 12)], 3, 4, 2, 2500, 1.0, 8))
     cases.append(([(5, 7), (33, 18), (64, 64)], 8, 3, 1, 3000, 1.05, 9))
+    # many levels / points: up to 8 levels stay on the binned backward; 9 levels, or more than 4
+    # points, take the generic backward; more than 47 samples per pair the plain D == 32 forward
+    pyr = [(24, 31), (12, 16), (6, 8), (3, 4), (2, 2), (1, 3), (5, 1), (1, 1), (7, 2)]
+    cases.append((pyr[:8], 2, 4, 2, 300, 1.2, 10))
+    cases.append((pyr[:6], 3, 1, 1, None, 1.0, 11))
+    cases.append((pyr[:9], 2, 2, 2, 150, 1.3, 12))
+    cases.append((pyr[:4], 2, 12, 1, 200, 1.1, 13))
+    cases.append((pyr[:2], 5, 8, 2, None, 1.0, 14))
     return cases
 
 
