@@ -16,7 +16,7 @@ buf = (ctypes.c_ulonglong * 16)()
 lib.msda_debug_phase_cycles(buf)
 for _ in range(5): MSDA.ms_deform_attn_backward(*args)
 lib.msda_debug_phase_cycles(buf)
-names = ["item setup/flush", "A: prefetch issue + max", "barrier 1", "C: rows->LDS, home push, zero, row prefetch", "C: scatter", "D accumulate", "E home grads", "barrier 2", "A: wait prefetched sample", "A: geometry", "A: atomics issue", "-"]
+names = ["item setup (decode, peek)", "A: prefetch issue + max", "barrier 1", "C: rows->LDS, home push, zero, row prefetch", "C: scatter", "D accumulate", "E home grads", "barrier 2", "A: wait prefetched sample", "A: geometry", "A: atomics issue", "item flush (stores issued)"]
 tot = sum(buf[i] for i in range(12))
 for i, nm in enumerate(names):
     print("%-30s %6.2f %%   %.3e cycles" % (nm, 100.0 * buf[i] / tot, buf[i]))
