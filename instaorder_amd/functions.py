@@ -73,26 +73,39 @@ class MSDeformAttnFusedFunction(Function):
 
 
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
-    """CPU-tensor path of the reference's ops/functions module (ms_deform_attn_func.py:52-72):
-    per level, bilinear ``grid_sample`` (zero padding, align_corners=False) of the level's map
-    viewed as [N*M, D, H, W] at ``2*loc - 1``, then the attention-weighted sum over L*P.
-
-    The reference reaches it for CPU inputs through the bare ``except`` of MSDeformAttn.forward
+    """CPU-tensor path with the name and signature of the reference's
+    ``ms_deform_attn_core_pytorch`` (ops/functions/ms_deform_attn_func.py:52-72), which the reference
+    reaches for CPU inputs through the bare ``except`` of MSDeformAttn.forward
     (ops/modules/ms_deform_attn.py:116-121; BASELINE.json configs[0]).  Here it is selected by
-    device, never by catching an error: GPU tensors always take the HIP kernels."""
+    device, never by catching an error: GPU tensors always take the HIP kernels.
+
+    Written as the op's own definition (the arithmetic of the HIP kernels, ``corner_setup`` in
+    csrc/msda_common.inc) rather than through ``grid_sample``: pixel coordinates
+    ``loc * (W, H) - 0.5``, the four neighbouring pixels gathered from the flattened level with
+    zero weight outside it, bilinear weights times the attention weight, summed over levels and
+    points.  Differentiable in value, locations and weights (gather / index arithmetic only)."""
     import torch
-    import torch.nn.functional as F
     n, _, m, d = value.shape
     lq, nl, npts = sampling_locations.shape[1], sampling_locations.shape[3], sampling_locations.shape[4]
-    sizes = [(int(h), int(w)) for h, w in value_spatial_shapes]
-    levels = value.split([h * w for h, w in sizes], dim=1)
-    grids = 2 * sampling_locations - 1
-    per_level = []
-    for lvl, (h, w) in enumerate(sizes):
-        fmap = levels[lvl].flatten(2).transpose(1, 2).reshape(n * m, d, h, w)
-        grid = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)
-        per_level.append(F.grid_sample(fmap, grid, mode="bilinear", padding_mode="zeros",
-                                       align_corners=False))
-    weights = attention_weights.transpose(1, 2).reshape(n * m, 1, lq, nl * npts)
-    out = (torch.stack(per_level, dim=-2).flatten(-2) * weights).sum(-1).view(n, m * d, lq)
-    return out.transpose(1, 2).contiguous()
+    out = value.new_zeros((n, lq, m, d))
+    start = 0
+    for lvl in range(nl):
+        h, w = int(value_spatial_shapes[lvl][0]), int(value_spatial_shapes[lvl][1])
+        level = value[:, start:start + h * w]                                  # [N, H*W, M, D]
+        start += h * w
+        xy = sampling_locations[:, :, :, lvl]                                  # [N, Lq, M, P, 2]
+        px, py = xy[..., 0] * w - 0.5, xy[..., 1] * h - 0.5
+        x0, y0 = torch.floor(px), torch.floor(py)
+        fx, fy = px - x0, py - y0
+        x0, y0 = x0.long(), y0.long()
+        acc = 0
+        for dy, wy in ((0, 1 - fy), (1, fy)):
+            for dx, wx in ((0, 1 - fx), (1, fx)):
+                xi, yi = x0 + dx, y0 + dy
+                inside = ((xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)).to(value.dtype)
+                flat = yi.clamp(0, h - 1) * w + xi.clamp(0, w - 1)             # [N, Lq, M, P]
+                idx = flat.permute(0, 1, 3, 2).reshape(n, lq * npts, m, 1).expand(-1, -1, -1, d)
+                rows = level.gather(1, idx).view(n, lq, npts, m, d).permute(0, 1, 3, 2, 4)
+                acc = acc + (wy * wx * inside).unsqueeze(-1) * rows            # [N, Lq, M, P, D]
+        out = out + (attention_weights[:, :, :, lvl].unsqueeze(-1) * acc).sum(3)
+    return out.reshape(n, lq, m * d)

@@ -90,6 +90,33 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     assert r2["unit"] == "imgs/s" and r2["value"] > 0
 
 
+def test_bench_self_launches_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no launcher in the environment starts its own two ranks
+    (fresh child processes under torch.distributed.run).  On this GPU-less host the ranks run the
+    control path only (MSDA_BENCH_REHEARSAL=1: gloo rendezvous, barriers, max over ranks, one JSON
+    line from rank 0, no kernels) -- what the driver's `--gpus N` command exercises around the
+    timed region."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MSDA_BENCH_REHEARSAL="1", OMP_NUM_THREADS="2")
+    if torch.cuda.is_available():
+        env["MSDA_BENCH_BACKEND"] = "gloo"      # two ranks sharing one GPU cannot use RCCL
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline", "--no-extras"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["unit"] == "Gsamples/s"
+    # without a GPU and without the rehearsal switch the ranks refuse to run: no CPU fallback
+    if not torch.cuda.is_available():
+        env.pop("MSDA_BENCH_REHEARSAL")
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                             capture_output=True, text=True, env=env, timeout=120)
+        assert bad.returncode != 0 and "no CPU fallback" in bad.stderr
+
+
 def test_config_c1_cpu_forward_512():
     """BASELINE.json configs[0]: CPU forward at the 512^2 shape (levels 16^2/32^2/64^2, S=5376)
     goes through the PyTorch path of the module -- the reference's CPU behaviour -- and agrees

@@ -59,3 +59,21 @@ def test_oracle_thread_count_independent(oracle):
         assert np.array_equal(x, y)
     if old is not None:
         os.environ["OMP_NUM_THREADS"] = old
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_product_cpu_path_vs_golden(name):
+    """instaorder_amd.ms_deform_attn_core_pytorch -- the product's CPU-tensor path (BASELINE.json
+    configs[0]; its own gather formulation, not grid_sample) -- against the reference's golden
+    outputs and autograd gradients, fp64."""
+    from instaorder_amd import ms_deform_attn_core_pytorch as core
+    c, g = cases.make_case(name), load_golden(name)
+    v = torch.from_numpy(c["value"]).requires_grad_(True)
+    loc = torch.from_numpy(c["loc"]).requires_grad_(True)
+    aw = torch.from_numpy(c["aw"]).requires_grad_(True)
+    out = core(v, torch.from_numpy(c["shapes"]), loc, aw)
+    out.backward(torch.from_numpy(c["grad_out"]))
+    assert rel_err(out.detach().numpy(), g["out"]) < 1e-12
+    assert rel_err(v.grad.numpy(), g["grad_value"]) < 1e-12
+    assert rel_err(loc.grad.numpy(), g["grad_loc"]) < 1e-11
+    assert rel_err(aw.grad.numpy(), g["grad_aw"]) < 1e-12
