@@ -28,7 +28,13 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // Host side.
 // ---------------------------------------------------------------------------------------
+// An error some other library left on this thread (hipGetLastError is per thread and sticky until
+// read) must not be reported as a failed MSDA launch: every entry point passes through check_dims,
+// which clears it first.
+void clear_stale_error() { (void)hipGetLastError(); }
+
 int check_dims(const char *who, int N, int S, int M, int D, int L, int Lq, int P) {
+  clear_stale_error();
   if (N < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0)
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "%s: bad dimensions batch=%d spatial_size=%d num_heads=%d channels=%d "
@@ -262,20 +268,20 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
   const uint32_t spi = (uint32_t)((size_t)Lq * M * L);          // quads per image
   const uint32_t bpi = (spi + binned::BIN_QB - 1) / binned::BIN_QB;
   const int cus = num_cus();
-  hipLaunchKernelGGL(binned::msda_bwd_bin_zero_kernel, dim3(cus), dim3(256), 0, st, shapes, N, M, L,
-                     key_cap, counts);
+  hipLaunchKernelGGL(binned::msda_bwd_bin_zero_kernel, dim3(cus), dim3(256), 0, st, shapes, lsi, N, S, M, L,
+                     Lq, P, key_cap, counts, grad_value, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   const uint64_t magic_ml = (((uint64_t)1 << 40) + (uint64_t)(M * L) - 1) / (uint64_t)(M * L);
   const uint64_t magic_l = (((uint64_t)1 << 40) + (uint64_t)L - 1) / (uint64_t)L;
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<false>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
+                     0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
                      entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
-  hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, N, M, L,
+  hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, lsi, N, S, M, L,
                      key_cap, counts, offs);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<true>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, loc, N, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
+                     0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
                      entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   // Small batches: fewer than ~8 tiles per workgroup means the kernel runs as long as its longest

@@ -152,3 +152,23 @@ def make_module_case():
     return dict(d_model=d_model, n_levels=n_levels, n_heads=n_heads, n_points=n_points,
                 shapes=shapes, lsi=level_start_index(shapes), state_dict=sd, query=query,
                 src=src, ref=ref, padding_mask=mask)
+
+
+# PositionEmbeddingSine fixtures: (key, constructor kwargs, input
+# shape [N, C, H, W], with a padding mask?)
+POSENC_CASES = [
+    ("enc_norm", dict(num_pos_feats=128, normalize=True), (2, 4, 6, 9), False),
+    ("enc_norm_masked", dict(num_pos_feats=128, normalize=True), (2, 4, 6, 9), True),
+    ("plain", dict(num_pos_feats=16, temperature=100), (1, 3, 5, 4), False),
+    ("scaled", dict(num_pos_feats=32, normalize=True, scale=3.0), (1, 2, 7, 3), True),
+]
+
+
+def posenc_mask(shape):
+    """Padding mask [N, H, W] (True = padded): image n is valid on its top-left (H-n-1) x (W-2n-1)."""
+    import torch
+    n, _, h, w = shape
+    mask = torch.ones((n, h, w), dtype=torch.bool)
+    for i in range(n):
+        mask[i, :h - i - 1, :w - 2 * i - 1] = False
+    return mask

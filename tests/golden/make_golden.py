@@ -40,7 +40,32 @@ def import_reference():
     return ms_deform_attn_core_pytorch, MSDeformAttn
 
 
+REF_POSENC = "/root/reference/mask2former/modeling/transformer_decoder/position_encoding.py"
+
+
+def position_encoding_golden():
+    """PositionEmbeddingSine (reference transformer_decoder/position_encoding.py:12-56; the file
+    imports nothing but torch), loaded by file path, on the encoder's configuration
+    (num_pos_feats = 128, normalize = True, pixel_decoder/msdeformattn.py:311-312) with and without
+    a padding mask, and on the un-normalised default."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_position_encoding", REF_POSENC)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for key, kw, shape, masked in cases.POSENC_CASES:
+        pe = mod.PositionEmbeddingSine(**kw)
+        x = torch.zeros(shape)
+        out[key] = pe(x, cases.posenc_mask(shape) if masked else None).numpy()
+    path = os.path.join(HERE, "position_encoding.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    position_encoding_golden()
+    if "--posenc-only" in sys.argv:
+        return
     core, MSDeformAttn = import_reference()
     torch.set_num_threads(4)
     for name in cases.CASES:

@@ -173,12 +173,14 @@ def test_runs_on_current_stream(msda):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("image,batch,dist", [(1024, 16, "model"), (1024, 4, "uniform"),
+@pytest.mark.parametrize("image,batch,dist", [(1024, 32, "model"), (1024, 16, "model"), (1024, 4, "uniform"),
                                               (1536, 2, "model")])
 def test_full_size_properties(msda, image, batch, dist):
-    """BASELINE.json sizes (C2: bs16 @1024^2; C5: 1536^2), fp32, size-independent properties:
-    forward is linear in value; backward's grad_value is the adjoint of that linear map;
-    sum_s aw_s * grad_aw_s = <grad_out, out> per pair; grad_value of a zero grad_out is zero."""
+    """BASELINE.json sizes (C3: bs32 @1024^2; C2: bs16 @1024^2; C5: 1536^2), fp32, size-independent
+    properties: forward is linear in value; backward's grad_value is the adjoint of that linear map;
+    sum_s aw_s * grad_aw_s = <grad_out, out> per pair; grad_sampling_loc equals the central
+    difference of the fp64 forward (exact for a bilinear function inside a pixel cell); grad_value
+    of a zero grad_out is zero."""
     from instaorder_amd import synthetic
     inp = synthetic.make_inputs(batch, synthetic.encoder_shapes(image), dist=dist, seed=1,
                                 device="cuda")
@@ -208,6 +210,42 @@ def test_full_size_properties(msda, image, batch, dist):
     gv0, gl0, ga0 = msda.ms_deform_attn_backward(v, ss, lsi, loc, aw, torch.zeros_like(go), 128)
     assert float(gv0.abs().max()) == 0.0 and float(gl0.abs().max()) == 0.0
     assert float(ga0.abs().max()) == 0.0
+    del gv0, gl0, ga0, v2, out2, out3
+    # d/d loc of ONE randomly chosen sample per (n, q, m) and coordinate: Phi = <go, F(loc)> is
+    # bilinear in a sample's pixel coordinates inside a pixel cell, so the central difference of
+    # the fp64 forward (generic kernels) over +-eps pixels is exact there; samples within 2*eps of
+    # a cell border are left out (the one-sided derivatives differ).
+    nb, lq, m_, nl, npt = aw.shape
+    gen = torch.Generator().manual_seed(5)
+    pick = torch.randint(0, nl * npt, (nb, lq, m_), generator=gen).cuda()
+    onehot = torch.nn.functional.one_hot(pick, nl * npt).view(nb, lq, m_, nl, npt).double()
+    wh = ss.flip(-1).double()                                       # (W_l, H_l)
+    eps_px = 1e-3
+    vd, awd, locd, god = v.double(), aw.double(), loc.double(), go.double().view(nb, lq, m_, d)
+    for axis in (0, 1):
+        size = wh[None, None, None, :, None, axis]
+        delta = torch.zeros_like(locd)
+        delta[..., axis] = onehot * eps_px / size
+        fp = msda.ms_deform_attn_forward(vd, ss, lsi, locd + delta, awd, 128).view(nb, lq, m_, d)
+        fm = msda.ms_deform_attn_forward(vd, ss, lsi, locd - delta, awd, 128).view(nb, lq, m_, d)
+        fd = ((fp - fm) * god).sum(-1) / (2 * eps_px)               # d Phi / d (pixel coordinate)
+        got = (gl.double()[..., axis] * onehot / size).sum((-1, -2))
+        pix = locd[..., axis] * size - 0.5
+        interior = (((pix - pix.round()).abs() > 2 * eps_px).double() * onehot).sum((-1, -2)) > 0.5
+        assert float(interior.double().mean()) > 0.95
+        err = ((got - fd).abs() * interior).max()
+        assert float(err) < GRAD_TOL_F32 * float(got.abs().max()), axis
+        del delta, fp, fm
+    # the fp64 generic backward (float atomics, another kernel altogether) agrees on all three
+    gv64, gl64, ga64 = msda.ms_deform_attn_backward(vd, ss, lsi, locd, awd, go.double(), 128)
+    near = torch.zeros_like(aw, dtype=torch.bool)
+    for axis in (0, 1):
+        pix = locd[..., axis] * wh[None, None, None, :, None, axis] - 0.5
+        near |= (pix - pix.round()).abs() < 1e-4                    # fp32 / fp64 may floor differently there
+    scale = float(gl64.abs().max())
+    assert float(((gl.double() - gl64).abs().amax(-1) * (~near)).max()) < GRAD_TOL_F32 * scale
+    assert float(((ga.double() - ga64).abs() * (~near)).max()) < GRAD_TOL_F32 * float(ga64.abs().max())
+    assert float((gv.double() - gv64).abs().max()) < GRAD_TOL_F32 * float(gv64.abs().max())
 
 
 def test_full_size_image_vs_oracle(msda, oracle):
@@ -215,6 +253,107 @@ def test_full_size_image_vs_oracle(msda, oracle):
     from instaorder_amd import synthetic
     inp = synthetic.make_inputs(1, synthetic.encoder_shapes(1024), dist="model", seed=2)
     _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
+
+
+@pytest.mark.parametrize("image,batch", [(1024, 3), (1536, 2)])
+def test_full_size_batches_vs_oracle(msda, oracle, image, batch):
+    """Several full-size images (3 at 1024^2; 2 at 1536^2 = C5's per-GPU shard) against the C oracle:
+    output and all three gradients, grad_sampling_loc included (the tile kernel's work queue walks
+    the images in an order that depends on the batch size).
+
+    Forward tolerance: 1e-5 at 1024^2, where the level sizes are powers of two and loc * size - 0.5
+    is exact in fp32.  At 1536^2 (W = 192, 96, 48) that pixel coordinate carries up to half an ulp
+    of 192 = 7.6e-6 px of fp32 rounding in ANY fp32 implementation -- the oracle run in fp32
+    (the reference kernel's arithmetic, ms_deform_im2col_cuda.cuh:290-291) is itself ~1e-5 away from
+    its fp64 run -- so there the bar is 3e-5 against fp64 and the fp32 oracle's own distance is
+    asserted to be of that size."""
+    from instaorder_amd import synthetic
+    inp = _off_lattice(synthetic.make_inputs(batch, synthetic.encoder_shapes(image), dist="model", seed=6))
+    fwd_tol = FWD_TOL_F32
+    if image == 1536:
+        n64 = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+        n32 = lambda k: inp[k].numpy()
+        keys = ("value", "spatial_shapes", "level_start_index", "sampling_locations", "attention_weights")
+        own = rel_err(oracle.forward(*[n32(k) for k in keys]), oracle.forward(*[n64(k) for k in keys]))
+        assert 3e-6 < own < 3e-5, own
+        fwd_tol = 3e-5
+    _oracle_check(msda, oracle, inp, fwd_tol, GRAD_TOL_F32)
+
+
+def _gapped(inp, lsi_new, s_new):
+    """The same levels laid out at other row offsets inside a value tensor of s_new rows."""
+    shapes = inp["spatial_shapes"].tolist()
+    old = inp["level_start_index"].tolist()
+    v = inp["value"]
+    vg = torch.randn((v.shape[0], s_new) + tuple(v.shape[2:]), generator=torch.Generator().manual_seed(1))
+    for (h, w), a, b in zip(shapes, old, lsi_new):
+        vg[:, b:b + h * w] = v[:, a:a + h * w]
+    out = dict(inp)
+    out["value"] = vg.contiguous()
+    out["level_start_index"] = torch.tensor(lsi_new, dtype=torch.int64)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_levels_that_do_not_cover_every_row(msda, oracle, dtype):
+    """spatial_size > sum(H*W) and gaps between the levels: rows that belong to no level get zero
+    grad_value (the reference's at::zeros_like, ms_deform_attn_cuda.cu:126), everything else is the
+    compact layout's result -- the binned kernels own whole rows and zero-fill nothing by default."""
+    from instaorder_amd import synthetic
+    shapes = [(9, 14), (20, 33), (40, 17)]
+    inp = synthetic.make_inputs(2, shapes, heads=4, channels=32, points=4, dist="uniform", seed=12,
+                                num_query=150)
+    inp["sampling_locations"] = inp["sampling_locations"] * 1.2 - 0.1
+    inp = _off_lattice(inp)
+    if dtype == torch.bfloat16:
+        inp["value"] = inp["value"].bfloat16().float()
+        inp["grad_output"] = inp["grad_output"].bfloat16().float()
+    lsi_new, s_new = [5, 5 + 126 + 3, 5 + 126 + 3 + 660 + 40], 5 + 126 + 3 + 660 + 40 + 680 + 11
+    gap = _gapped(inp, lsi_new, s_new)
+    n = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    o_out = oracle.forward(n("value"), n("spatial_shapes"), n("level_start_index"),
+                           n("sampling_locations"), n("attention_weights"))
+    o_gv, o_gl, o_ga = oracle.backward(n("value"), n("spatial_shapes"), n("level_start_index"),
+                                       n("sampling_locations"), n("attention_weights"), n("grad_output"))
+    want_gv = np.zeros((2, s_new, 4, 32))
+    for (h, w), a, b in zip(shapes, inp["level_start_index"].tolist(), lsi_new):
+        want_gv[:, b:b + h * w] = o_gv[:, a:a + h * w]
+    dev = {k: v.cuda() for k, v in gap.items()}
+    args = (dev["value"].to(dtype), dev["spatial_shapes"], dev["level_start_index"],
+            dev["sampling_locations"], dev["attention_weights"])
+    out = msda.ms_deform_attn_forward(*args, 128).float().cpu().numpy()
+    gv, gl, ga = (t.float().cpu().numpy() for t in
+                  msda.ms_deform_attn_backward(*args, dev["grad_output"].to(dtype), 128))
+    assert rel_err(out, o_out) < (FWD_TOL_F32 if dtype == torch.float32 else 1e-2)
+    assert rel_err(gv, want_gv) < GRAD_TOL_F32
+    assert rel_err(gl, o_gl) < GRAD_TOL_F32
+    assert rel_err(ga, o_ga) < GRAD_TOL_F32
+    covered = np.zeros(s_new, dtype=bool)
+    for (h, w), b in zip(shapes, lsi_new):
+        covered[b:b + h * w] = True
+    assert float(np.abs(gv[:, ~covered]).max()) == 0.0
+
+
+def test_levels_that_leave_the_value_tensor_or_overlap(msda):
+    """spatial_size < sum(H*W) (the reference would read and write out of bounds) or two levels
+    sharing rows: the channels == 32 backward returns zeros in all three gradients instead of
+    uninitialised memory, and touches nothing outside its tensors."""
+    from instaorder_amd import synthetic
+    shapes = [(16, 16), (32, 32)]
+    inp = synthetic.make_inputs(2, shapes, heads=4, channels=32, points=4, dist="uniform", seed=3,
+                                num_query=90, device="cuda")
+    v, ss, loc, aw, go = (inp[k] for k in ("value", "spatial_shapes", "sampling_locations",
+                                           "attention_weights", "grad_output"))
+    guard = torch.full((v.numel() + 4096,), 3.0, device="cuda")       # outputs carved out of guarded memory
+    for lsi, s_rows in ((torch.tensor([0, 256]), 1000),                # too few rows for level 1
+                        (torch.tensor([0, 100]), 1280),                # level 1 starts inside level 0
+                        (torch.tensor([-3, 256]), 1280)):              # negative start
+        vv = v[:, :s_rows].contiguous()
+        gvs, gls, gas = msda.ms_deform_attn_backward(vv, ss, lsi.cuda(), loc, aw, go, 128)
+        torch.cuda.synchronize()
+        for t in (gvs, gls, gas):
+            assert float(t.abs().max()) == 0.0
+    assert float((guard - 3.0).abs().max()) == 0.0
 
 
 def test_module_gpu_matches_reference_golden(msda):
@@ -542,6 +681,53 @@ def test_fused_entry_points_match_unfused(msda, shapes, heads, points, num_query
     assert rel_err(n(value.grad), n(gv_ref)) < GRAD_TOL_F32
     assert rel_err(n(off_f.grad), n(goff_ref)) < GRAD_TOL_F32
     assert rel_err(n(logits_f.grad), n(glog_ref)) < GRAD_TOL_F32
+
+
+@pytest.mark.parametrize("shapes,heads,points,num_query,batch", [
+    ([(8, 8), (16, 16), (32, 32)], 8, 4, None, 2),
+    ([(7, 9), (5, 3)], 3, 3, 37, 3),
+])
+def test_fused_entry_points_vs_oracle(msda, oracle, shapes, heads, points, num_query, batch):
+    """The fused entry points against the C ORACLE (not against the unfused HIP path): softmax and
+    location arithmetic of the caller (ops/modules/ms_deform_attn.py:102-109) done in fp64 PyTorch
+    on the CPU, the oracle's forward/backward on those, and the chain rule back to offsets and
+    logits, also in fp64."""
+    from instaorder_amd import ext
+    inp, ref, off, logits = _fused_inputs(batch, shapes, heads, points, num_query, seed=13)
+    n_, lq, m_, nl, p_, _ = off.shape
+    ss = inp["spatial_shapes"]
+    # fp32 arithmetic of the caller decides the locations the kernels see; redo it in fp32, then
+    # move locations off the pixel lattice by nudging the offsets (the derivative is one-sided there)
+    norm32 = torch.stack([ss[..., 1], ss[..., 0]], -1).float()
+    loc32 = ref[:, :, None, :, None, :] + off / norm32[None, None, None, :, None, :]
+    tmp = {"sampling_locations": loc32.clone(), "spatial_shapes": ss}
+    moved = _off_lattice(tmp)["sampling_locations"]
+    off = (off + (moved - loc32) * norm32[None, None, None, :, None, :]).contiguous()
+    offd = off.double().requires_grad_(True)
+    logd = logits.double().requires_grad_(True)
+    norm = norm32.double()
+    locd = ref.double()[:, :, None, :, None, :] + offd / norm[None, None, None, :, None, :]
+    awd = torch.softmax(logd, -1).view(n_, lq, m_, nl, p_)
+    npy = lambda t: t.detach().numpy()
+    vnp, ssnp, lsinp = inp["value"].double().numpy(), ss.numpy(), inp["level_start_index"].numpy()
+    o_out = oracle.forward(vnp, ssnp, lsinp, npy(locd), npy(awd))
+    o_gv, o_gl, o_ga = oracle.backward(vnp, ssnp, lsinp, npy(locd), npy(awd), inp["grad_output"].double().numpy())
+    (locd * torch.from_numpy(o_gl)).sum().backward(retain_graph=True)
+    (awd * torch.from_numpy(o_ga)).sum().backward()
+    dev = {k: v.cuda() for k, v in inp.items()}
+    before = ext.launch_count()
+    out = ext.ms_deform_attn_fused_forward(dev["value"], dev["spatial_shapes"], dev["level_start_index"],
+                                           ref.cuda(), off.cuda(), logits.cuda())
+    gv, goff, glog = ext.ms_deform_attn_fused_backward(dev["value"], dev["spatial_shapes"],
+                                                       dev["level_start_index"], ref.cuda(), off.cuda(),
+                                                       logits.cuda(), dev["grad_output"])
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 4
+    c = lambda t: t.cpu().numpy()
+    assert rel_err(c(out), o_out) < FWD_TOL_F32
+    assert rel_err(c(gv), o_gv) < GRAD_TOL_F32
+    assert rel_err(c(goff), npy(offd.grad)) < GRAD_TOL_F32
+    assert rel_err(c(glog), npy(logd.grad)) < GRAD_TOL_F32
 
 
 def test_fused_reference_point_gradient_and_limits(msda):

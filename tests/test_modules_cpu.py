@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 import cases
@@ -60,6 +61,17 @@ def test_encoder_stack_structure_and_grad_flow():
     ref = enc.encoder.get_reference_points(shapes, torch.ones(2, 3, 2), "cpu")
     assert tuple(ref.shape) == (2, 126, 3, 2)
     assert torch.allclose(ref[0, 0, 0], torch.tensor([0.5 / 3, 0.5 / 2]))       # first pixel centre (x, y)
+
+
+@pytest.mark.parametrize("key,kw,shape,masked", cases.POSENC_CASES)
+def test_position_embedding_sine_matches_reference_golden(key, kw, shape, masked):
+    """instaorder_amd.encoder.PositionEmbeddingSine against outputs of the reference's own class
+    (transformer_decoder/position_encoding.py:12-56, loaded by file path in make_golden.py)."""
+    from instaorder_amd.encoder import PositionEmbeddingSine
+    want = load_golden("position_encoding")[key]
+    got = PositionEmbeddingSine(**kw)(torch.zeros(shape), cases.posenc_mask(shape) if masked else None)
+    assert got.shape == want.shape
+    assert float((got - torch.from_numpy(want)).abs().max()) < 1e-6
 
 
 def test_shard_batch_covers_the_batch():
