@@ -104,6 +104,28 @@ int msda_backward_f32_ws(const float *value, const int64_t *spatial_shapes,
                          float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/*
+ * msda_backward_f32 for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): same arguments, same results, and no hipMalloc /
+ * hipFree / pool allocation anywhere.  No counterpart in the reference (its launcher allocates
+ * through ATen, src/cuda/ms_deform_attn_cuda.cu:126-128).  The sort-by-tile workspace is a
+ * 64 MiB array built into the library's code object (each GPU the library runs on holds its copy
+ * until the process ends); a problem whose msda_backward_workspace_bytes(...) exceeds
+ * msda_backward_noalloc_max_workspace_bytes() -- more than about 970,000 (image, query, head,
+ * level) quads, e.g. more than one 1024^2 image of the encoder shape -- is rejected with
+ * MSDA_ERR_INVALID_ARGUMENT (use msda_backward_f32_ws).  Shapes off the channels == 32 fast path
+ * run the generic kernels, which need no workspace.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (different streams or threads) race; order them on one stream.
+ */
+int msda_backward_f32_noalloc(const float *value, const int64_t *spatial_shapes,
+                              const int64_t *level_start_index, const float *sampling_loc,
+                              const float *attn_weight, const float *grad_output, int batch,
+                              int spatial_size, int num_heads, int channels, int num_levels,
+                              int num_query, int num_point, float *grad_value,
+                              float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
+size_t msda_backward_noalloc_max_workspace_bytes(void);
+
 int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
                       const int64_t *level_start_index, const double *sampling_loc,
                       const double *attn_weight, const double *grad_output, int batch,

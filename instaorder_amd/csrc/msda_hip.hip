@@ -355,6 +355,60 @@ int backward_f32(const char *who, const float *value, const int64_t *shapes, con
                                 grad_value, grad_loc, grad_aw, st);
 }
 
+// ---- one entry point that allocates nothing (include/msda_hip.h: msda_backward_f32_noalloc) ----
+// The sort-by-tile workspace of the binned backward lives in a file-scope device array instead of
+// coming from an allocator.  Each GPU the library runs on holds its own copy of the array at its own
+// address; host code never uses the array's NAME as a pointer (that is a host-side stand-in, not a
+// device address) -- it asks hipGetSymbolAddress once per device, with that device current, and
+// passes the returned pointer to the kernels like any other workspace.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char g_noalloc_scratch[NOALLOC_SCRATCH_BYTES];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::atomic<void *> g_noalloc_ptr[NOALLOC_MAX_DEVICES];
+
+// Device address of the scratch array on the current device (looked up on the first call per device).
+int noalloc_scratch(const char *who, void **out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(MSDA_ERR_LAUNCH, "%s: hipGetDevice failed: %s", who, hipGetErrorString(e));
+  if (dev < 0 || dev >= NOALLOC_MAX_DEVICES)
+    return fail(MSDA_ERR_INVALID_ARGUMENT, "%s: device ordinal %d is beyond the %d this entry point tracks", who,
+                dev, NOALLOC_MAX_DEVICES);
+  void *p = g_noalloc_ptr[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+    if (e != hipSuccess || p == nullptr)
+      return fail(MSDA_ERR_LAUNCH, "%s: hipGetSymbolAddress(scratch) failed on device %d: %s", who, dev,
+                  hipGetErrorString(e));
+    g_noalloc_ptr[dev].store(p, std::memory_order_release);   // racing first calls store the same address
+  }
+  *out = p;
+  return MSDA_OK;
+}
+
+int backward_f32_noalloc(const char *who, const float *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *loc, const float *aw, const float *grad_out, int N, int S, int M, int D,
+                         int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw, void *stream) {
+  if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
+  const bool fast = binned_shape(N, S, M, D, L, Lq, P) && aligned16(value) && aligned16(grad_out) &&
+                    aligned16(grad_value) && aligned16(loc) && aligned16(grad_loc) && bwd_impl_choice() != 0;
+  if (!fast)   // the generic kernels use no scratch buffer at all (one hipMemsetAsync, no allocation)
+    return backward_atomic<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P, grad_value,
+                                  grad_loc, grad_aw, static_cast<hipStream_t>(stream));
+  const size_t need = binned_workspace_bytes(N, S, M, L, Lq, P);
+  if (need > NOALLOC_SCRATCH_BYTES)
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "%s: this problem needs %zu bytes of sort workspace, more than the %zu-byte built-in scratch "
+                "buffer (about 970,000 (image, query, head, level) quads); use msda_backward_f32_ws with a "
+                "caller-provided workspace", who, need, NOALLOC_SCRATCH_BYTES);
+  void *scratch = nullptr;
+  if (int rc = noalloc_scratch(who, &scratch)) return rc;
+  return launch_backward_binned<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P, grad_value,
+                                       grad_loc, grad_aw, scratch, NOALLOC_SCRATCH_BYTES,
+                                       static_cast<hipStream_t>(stream));
+}
+
 int backward_bf16(const char *who, const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                   const float *loc, const float *aw, const uint16_t *grad_out, int N, int S, int M,
                   int D, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw,
@@ -566,6 +620,20 @@ int msda_backward_f32_ws(const float *value, const int64_t *spatial_shapes,
                       num_query, num_point, grad_value, grad_sampling_loc, grad_attn_weight,
                       workspace, workspace_bytes, false, stream);
 }
+
+int msda_backward_f32_noalloc(const float *value, const int64_t *spatial_shapes,
+                              const int64_t *level_start_index, const float *sampling_loc,
+                              const float *attn_weight, const float *grad_output, int batch,
+                              int spatial_size, int num_heads, int channels, int num_levels,
+                              int num_query, int num_point, float *grad_value, float *grad_sampling_loc,
+                              float *grad_attn_weight, void *stream) {
+  return backward_f32_noalloc("msda_backward_f32_noalloc", value, spatial_shapes, level_start_index,
+                              sampling_loc, attn_weight, grad_output, batch, spatial_size, num_heads,
+                              channels, num_levels, num_query, num_point, grad_value, grad_sampling_loc,
+                              grad_attn_weight, stream);
+}
+
+size_t msda_backward_noalloc_max_workspace_bytes(void) { return NOALLOC_SCRATCH_BYTES; }
 
 size_t msda_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
                                      int num_levels, int num_query, int num_point) {

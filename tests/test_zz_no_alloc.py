@@ -1,0 +1,79 @@
+"""GPU: msda_backward_f32_noalloc -- the one entry point that allocates nothing (its sort workspace
+is a device array built into the library) -- called through the C ABI and checked against
+msda_backward_f32_ws (caller-provided workspace) on the same inputs: two calls in a row, the second
+on a smaller input, so whatever the first call left in the shared scratch array must not leak into
+the second.  Tolerance: the order of a tile's list, hence of the fp32 sums, is not fixed from run to
+run (tests/test_gpu_parity.py::test_backward_run_to_run_agreement), so "equal" means equal to
+rounding; against the north-star's 1e-4 gradient bar this is 10x tighter.
+
+Collected last (file name) so a failure here cannot hide another test behind `pytest -x`."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+ORDER_TOL = 1e-5
+
+
+def _call(lib, fn, inp, *extra):
+    v, ss, lsi = inp["value"], inp["spatial_shapes"], inp["level_start_index"]
+    loc, aw, go = inp["sampling_locations"], inp["attention_weights"], inp["grad_output"]
+    n, s, m, d = v.shape
+    nl, lq, p = ss.shape[0], loc.shape[1], loc.shape[4]
+    gv, gl, ga = torch.full_like(v, 7.0), torch.full_like(loc, 7.0), torch.full_like(aw, 7.0)
+    rc = fn(v.data_ptr(), ss.data_ptr(), lsi.data_ptr(), loc.data_ptr(), aw.data_ptr(), go.data_ptr(),
+            n, s, m, d, nl, lq, p, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *extra,
+            torch.cuda.current_stream().cuda_stream)
+    return rc, gv, gl, ga
+
+
+def _dims(inp):
+    v, ss, loc = inp["value"], inp["spatial_shapes"], inp["sampling_locations"]
+    n, s, m, d = v.shape
+    return n, s, m, d, ss.shape[0], loc.shape[1], loc.shape[4]
+
+
+def test_no_alloc_backward_matches_workspace_backward():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    from instaorder_amd import ext, synthetic
+    lib = ext._load()
+    I, P = ctypes.c_int, ctypes.c_void_p
+    lib.msda_backward_f32_noalloc.argtypes = [P] * 6 + [I] * 7 + [P] * 4
+    lib.msda_backward_f32_noalloc.restype = I
+    lib.msda_backward_noalloc_max_workspace_bytes.restype = ctypes.c_size_t
+    cap = int(lib.msda_backward_noalloc_max_workspace_bytes())
+    assert cap == 64 << 20
+
+    big = synthetic.make_inputs(2, synthetic.encoder_shapes(512), dist="model", seed=31, device="cuda")
+    small = synthetic.make_inputs(1, [(5, 9), (20, 13)], heads=3, channels=32, points=2, dist="uniform",
+                                  seed=32, num_query=41, device="cuda")
+    generic = synthetic.make_inputs(1, [(6, 4), (3, 2)], heads=2, channels=30, points=2, dist="uniform",
+                                    seed=33, num_query=9, device="cuda")       # D = 30: no workspace at all
+    for inp in (big, small, big, generic):
+        need = int(lib.msda_backward_workspace_bytes(*_dims(inp)))
+        assert need <= cap
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+        rc, gv0, gl0, ga0 = _call(lib, lib.msda_backward_f32_ws, inp, ws.data_ptr(), need)
+        assert rc == 0, lib.msda_last_error()
+        torch.cuda.synchronize()
+        # no allocation between here and the synchronize: outputs exist already
+        before = ext.launch_count()
+        rc, gv, gl, ga = _call(lib, lib.msda_backward_f32_noalloc, inp)
+        assert rc == 0, lib.msda_last_error()
+        torch.cuda.synchronize()
+        assert ext.launch_count() > before
+        for got, want in ((gv, gv0), (gl, gl0), (ga, ga0)):
+            assert torch.isfinite(got).all()
+            assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
+
+    # a problem whose workspace exceeds the built-in array is refused, outputs untouched
+    huge = synthetic.make_inputs(2, synthetic.encoder_shapes(1024), dist="model", seed=34, device="cuda")
+    assert int(lib.msda_backward_workspace_bytes(*_dims(huge))) > cap
+    rc, gv, gl, ga = _call(lib, lib.msda_backward_f32_noalloc, huge)
+    assert rc == 1 and b"built-in scratch" in lib.msda_last_error()
+    torch.cuda.synchronize()
+    assert float((gv - 7.0).abs().max()) == 0.0 and float((ga - 7.0).abs().max()) == 0.0
