@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd "$R"
 run() {  # name args...
   local name=$1; shift
-  timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > "$OUT/bench_$name.json" || { echo "$name failed"; exit 1; }
+  timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras "$@" > "$OUT/bench_$name.json" || { echo "$name failed"; exit 1; }
   python - "$OUT/bench_$name.json" "$name" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -8,5 +8,5 @@ OUT=$R/gpurun_out/$1; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- \
-  python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/err.log" || { tail -5 "$OUT/err.log"; exit 1; }
+  python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" > "$OUT/bench.json" 2> "$OUT/err.log" || { tail -5 "$OUT/err.log"; exit 1; }
 cut -d, -f1-8 "$OUT"/run_kernel_stats.csv | head -14

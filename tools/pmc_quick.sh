@@ -4,7 +4,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$1; shift
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {
