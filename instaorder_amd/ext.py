@@ -181,11 +181,25 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
 # Fused boundary (opt-in): the op plus the softmax and the
 # sampling-location arithmetic of its caller (reference ops/modules/ms_deform_attn.py:102-109).
 # ---------------------------------------------------------------------------------------------
-def fused_forward_supported(value, reference_points, num_levels, num_point):
-    """True when msda_fused_forward_f32 takes the call (else use the unfused functions)."""
-    return (value.is_cuda and value.dtype in (torch.float32, torch.bfloat16) and value.dim() == 4
-            and value.shape[3] == 32
-            and reference_points.shape[-1] == 2 and num_levels * num_point <= 16)
+def fused_forward_supported(value, reference_points, num_levels, num_point, sampling_offsets=None,
+                            attn_logits=None):
+    """True when the fused entry points take the call (else use the unfused functions): every
+    precondition of msda_fused_forward_* / msda_fused_backward_* and of _fused_common -- a GPU value
+    of 32 channels per head in fp32 or bf16, fp32 reference points [N,Lq,L,2] / offsets / logits,
+    num_levels * num_point <= 16, tensors of < 2^30 elements, a non-empty batch."""
+    if not (value.is_cuda and value.dtype in (torch.float32, torch.bfloat16) and value.dim() == 4
+            and value.shape[3] == 32 and reference_points.dim() == 4 and reference_points.shape[-1] == 2
+            and reference_points.dtype == torch.float32 and num_levels * num_point <= 16):
+        return False
+    side = [t for t in (sampling_offsets, attn_logits) if t is not None]
+    if any(t.dtype != torch.float32 or not t.is_cuda for t in side):
+        return False
+    limit = 1 << 30
+    n, _, m, _ = value.shape
+    lq = reference_points.shape[1]
+    if value.numel() >= limit or n * lq * m * num_levels * num_point * 2 >= limit or n * lq * m * 32 >= limit:
+        return False
+    return n * lq > 0 and value.numel() > 0
 
 
 def _fused_common(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,

@@ -78,7 +78,7 @@ class MSDeformAttn(nn.Module):
         offsets = self.sampling_offsets(query).view(n, len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(n, len_q, self.n_heads, self.n_levels * self.n_points)
         if self.fused_prologue and ext.fused_forward_supported(value, reference_points, self.n_levels,
-                                                               self.n_points):
+                                                               self.n_points, offsets, weights):
             output = MSDeformAttnFusedFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                                      reference_points.contiguous(), offsets, weights)
             return self.output_proj(output)

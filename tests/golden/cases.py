@@ -172,3 +172,52 @@ def posenc_mask(shape):
     for i in range(n):
         mask[i, :h - i - 1, :w - 2 * i - 1] = False
     return mask
+
+
+# Encoder-stack fixtures: MSDeformAttnTransformerEncoderOnly of the reference
+# (pixel_decoder/msdeformattn.py:23-254).  Parameters are drawn here, by name and shape, so that the generator
+# (which loads them into the reference's class) and the tests (which load them into the mirror) agree.
+ENCODER_CASES = {
+    "small": dict(kwargs=dict(d_model=64, nhead=4, num_encoder_layers=2, dim_feedforward=96, dropout=0.0,
+                              num_feature_levels=3, enc_n_points=2, use_adapters=True, adapter_dim=16,
+                              adapter_scale=0.1),
+                  shapes=[(3, 4), (5, 3), (6, 7)], batch=2, seed=501),
+    "heads8": dict(kwargs=dict(d_model=256, nhead=8, num_encoder_layers=2, dim_feedforward=128, dropout=0.0,
+                               num_feature_levels=3, enc_n_points=4, use_adapters=False),
+                   shapes=[(2, 3), (4, 5), (8, 8)], batch=1, seed=502),          # 32 channels per head: the HIP fast path
+}
+
+
+def make_encoder_case(key):
+    spec = ENCODER_CASES[key]
+    kw, rs = spec["kwargs"], np.random.RandomState(spec["seed"])
+    d, m, nl, npts = kw["d_model"], kw["nhead"], kw["num_feature_levels"], kw["enc_n_points"]
+    ffn = kw["dim_feedforward"]
+
+    def w(*shape, scale=0.1):
+        return _f32(scale * rs.standard_normal(shape))
+
+    sd = {"level_embed": w(nl, d, scale=0.5)}
+    for i in range(kw["num_encoder_layers"]):
+        pre = "encoder.layers.%d." % i
+        sd[pre + "self_attn.sampling_offsets.weight"] = w(m * nl * npts * 2, d, scale=0.05)
+        sd[pre + "self_attn.sampling_offsets.bias"] = w(m * nl * npts * 2, scale=1.5)        # pixels
+        sd[pre + "self_attn.attention_weights.weight"] = w(m * nl * npts, d, scale=0.1)
+        sd[pre + "self_attn.attention_weights.bias"] = w(m * nl * npts, scale=0.5)
+        for name in ("value_proj", "output_proj"):
+            sd[pre + "self_attn.%s.weight" % name] = w(d, d)
+            sd[pre + "self_attn.%s.bias" % name] = w(d)
+        for name in ("norm1", "norm2"):
+            sd[pre + name + ".weight"] = _f32(1.0 + 0.1 * rs.standard_normal(d))
+            sd[pre + name + ".bias"] = w(d)
+        sd[pre + "linear1.weight"], sd[pre + "linear1.bias"] = w(ffn, d), w(ffn)
+        sd[pre + "linear2.weight"], sd[pre + "linear2.bias"] = w(d, ffn), w(d)
+        if kw.get("use_adapters"):
+            ad = kw["adapter_dim"]
+            sd[pre + "adapter.0.weight"], sd[pre + "adapter.0.bias"] = w(ad, d), w(ad)
+            sd[pre + "adapter.2.weight"], sd[pre + "adapter.2.bias"] = w(d, ad), w(d)
+    n = spec["batch"]
+    srcs = [_f32(rs.standard_normal((n, d, h, ww))) for h, ww in spec["shapes"]]
+    pos = [_f32(0.5 * rs.standard_normal((n, d, h, ww))) for h, ww in spec["shapes"]]
+    s = sum(h * ww for h, ww in spec["shapes"])
+    return dict(kwargs=kw, state_dict=sd, srcs=srcs, pos=pos, grad_memory=_f32(rs.standard_normal((n, s, d))))

@@ -62,8 +62,81 @@ def position_encoding_golden():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def import_reference_encoder():
+    """The reference's encoder classes (pixel_decoder/msdeformattn.py:23-254) without detectron2.
+
+    msdeformattn.py imports detectron2 / fvcore NAMES at module scope (configurable, Conv2d, ShapeSpec,
+    get_norm, SEM_SEG_HEADS_REGISTRY, weight_init) that only the pixel-decoder class below the encoder
+    classes uses, and sits in the `mask2former` package whose __init__ pulls in all of detectron2.  Empty
+    placeholder modules are registered for those names and for the enclosing packages (their __path__ set to
+    the reference's directories so that the real position_encoding.py, transformer.py and ops/ files load);
+    nothing the encoder classes execute comes from a placeholder.  Returns the module."""
+    import importlib
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("MultiScaleDeformableAttention", types.ModuleType("MultiScaleDeformableAttention"))
+    root = "/root/reference/mask2former"
+
+    def pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+        return m
+
+    pkg("mask2former", root)
+    pkg("mask2former.modeling", root + "/modeling")
+    pkg("mask2former.modeling.pixel_decoder", root + "/modeling/pixel_decoder")
+    pkg("mask2former.modeling.transformer_decoder", root + "/modeling/transformer_decoder")
+
+    class _Registry:
+        def register(self):
+            return lambda cls: cls
+
+    def placeholder(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    placeholder("fvcore")
+    placeholder("fvcore.nn", weight_init=placeholder("fvcore.nn.weight_init"))
+    placeholder("detectron2")
+    placeholder("detectron2.config", configurable=lambda f=None, **kw: f if f is not None else (lambda g: g))
+    placeholder("detectron2.layers", Conv2d=None, ShapeSpec=None, get_norm=None)
+    placeholder("detectron2.modeling", SEM_SEG_HEADS_REGISTRY=_Registry())
+    return importlib.import_module("mask2former.modeling.pixel_decoder.msdeformattn")
+
+
+def encoder_golden():
+    """MSDeformAttnTransformerEncoderOnly of the reference (pixel_decoder/msdeformattn.py:23-123, with its
+    encoder layers :126-206 and get_reference_points :216-229), fp64 on the CPU -- the op inside takes the
+    reference's ms_deform_attn_core_pytorch path -- on the seeded inputs and parameters of
+    cases.make_encoder_case(): output memory and the gradients of the inputs."""
+    ref = import_reference_encoder()
+    for key in cases.ENCODER_CASES:
+        ec = cases.make_encoder_case(key)
+        enc = ref.MSDeformAttnTransformerEncoderOnly(**ec["kwargs"]).double()
+        missing = set(enc.state_dict().keys()) ^ set(ec["state_dict"].keys())
+        assert not missing, missing
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in ec["state_dict"].items()})
+        enc.eval()
+        srcs = [torch.from_numpy(x).requires_grad_(True) for x in ec["srcs"]]
+        pos = [torch.from_numpy(x) for x in ec["pos"]]
+        memory, shapes, lsi = enc(srcs, pos)
+        memory.backward(torch.from_numpy(ec["grad_memory"]))
+        out = {"memory": memory.detach().numpy(), "shapes": shapes.numpy(), "lsi": lsi.numpy()}
+        for i, x in enumerate(srcs):
+            out["grad_src%d" % i] = x.grad.numpy()
+        if key == "heads8":        # compared in fp32 on the GPU: stored in fp32 to stay small
+            out = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in out.items()}
+        path = os.path.join(HERE, "encoder_%s.npz" % key)
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
     position_encoding_golden()
+    if "--encoder-only" in sys.argv:
+        return encoder_golden()
     if "--posenc-only" in sys.argv:
         return
     core, MSDeformAttn = import_reference()

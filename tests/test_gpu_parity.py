@@ -161,6 +161,45 @@ def test_empty_and_degenerate(msda):
         assert float(t.abs().sum()) == 0.0
 
 
+def test_non_finite_value_under_zero_weight_reads(msda, oracle):
+    """Pins the one documented divergence for non-finite VALUES (parity
+    unpinned in the reference, whose tests hold no such case).  The D == 32 forward is branch-free:
+    a corner outside the level is read from a clamped in-level address with weight 0, and a sample
+    whose gate is closed reads the level's first pixels with four zero weights, where the reference
+    skips the loads (ms_deform_im2col_cuda.cuh:61-83, :293).  An Inf in such a pixel therefore turns
+    0 * Inf into NaN for the (query, head) pairs that own those samples -- where the reference gives
+    the finite sum of the remaining samples.  Allowed here: the reference's value or NaN, nothing
+    else; every other output element is the reference's; and the backward, which masks rows by
+    ok-flags and never forms that product, gives the oracle's finite gradients for locations and
+    weights everywhere."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(1, [(8, 8)], heads=2, channels=32, points=4, dist="uniform", seed=17,
+                                num_query=64)
+    loc = inp["sampling_locations"]
+    loc[...] = 0.3 + 0.5 * loc                          # every sample well inside, away from pixel (0, 0) ...
+    loc[0, :8, 0, 0, :2] = 7.5                          # ... but two samples of head 0 of queries 0-7: gate closed
+    inp["value"][0, 0, 0, :] = float("inf")             # Inf in pixel (0, 0) of head 0, which no open sample touches
+    dev = {k: v.cuda() for k, v in inp.items()}
+    args = (dev["value"], dev["spatial_shapes"], dev["level_start_index"], dev["sampling_locations"],
+            dev["attention_weights"])
+    out = msda.ms_deform_attn_forward(*args, 128).cpu().view(1, 64, 2, 32)
+    n = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    oargs = (n("value"), n("spatial_shapes"), n("level_start_index"), n("sampling_locations"), n("attention_weights"))
+    want = torch.from_numpy(oracle.forward(*oargs).reshape(1, 64, 2, 32))
+    assert torch.isfinite(want).all()                   # the reference never reads the Inf
+    affected = torch.zeros(1, 64, 2, dtype=torch.bool)
+    affected[0, :8, 0] = True
+    ok = ~affected
+    assert rel_err(out[ok].numpy(), want[ok].numpy()) < FWD_TOL_F32
+    got = out[affected]
+    close = (got - want[affected].float()).abs() <= FWD_TOL_F32 * float(want.abs().max())
+    assert bool((close | torch.isnan(got)).all())
+    gv, gl, ga = msda.ms_deform_attn_backward(*args, dev["grad_output"], 128)
+    o_gv, o_gl, o_ga = oracle.backward(*oargs, n("grad_output"))
+    assert rel_err(gl.cpu().numpy(), o_gl) < GRAD_TOL_F32 and rel_err(ga.cpu().numpy(), o_ga) < GRAD_TOL_F32
+    assert rel_err(gv.cpu().numpy(), o_gv) < GRAD_TOL_F32
+
+
 def test_runs_on_current_stream(msda):
     c = cases.make_case("batch4")
     value, shapes, lsi, loc, aw, go = _dev(c, torch.float32)
@@ -403,6 +442,22 @@ def test_encoder_stack_gpu_runs_hip_path(msda):
     cpu.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
     ref, _, _ = cpu([x.cpu() for x in srcs], [pe(x.cpu()) for x in srcs])
     assert rel_err(memory.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("key", sorted(cases.ENCODER_CASES))
+def test_encoder_stack_gpu_matches_reference_golden(msda, key):
+    """Row f1 on the GPU: the encoder stack with the HIP op inside every layer (fp32; 'heads8' has 32
+    channels per head = the fast kernels, 'small' takes the generic ones) against the REFERENCE encoder's
+    fp64 output and input gradients (tests/golden/encoder_*.npz)."""
+    from instaorder_amd import ext
+    from test_modules_cpu import _encoder_case
+    before = ext.launch_count()
+    g, memory, shapes, lsi, srcs = _encoder_case(key, torch.float32, "cuda")
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 4          # two layers: forward and backward of each
+    assert rel_err(memory.detach().cpu().numpy(), g["memory"]) < 2e-5       # fp32 linears / LayerNorm around the op
+    for i, x in enumerate(srcs):
+        assert rel_err(x.grad.cpu().numpy(), g["grad_src%d" % i]) < 1e-4
 
 
 BF16_TOL = 1e-2       # north-star tolerance of the bf16 variant (BASELINE.md section 2)
@@ -783,6 +838,27 @@ def test_module_fused_prologue_matches_default(msda):
     assert rel_err(outs[1], outs[0]) < FWD_TOL_F32
     for k in grads[0]:
         assert rel_err(grads[1][k], grads[0][k]) < GRAD_TOL_F32, k
+
+
+def test_module_fused_prologue_falls_back_when_unsupported(msda):
+    """fused_prologue=True on inputs the fused entry points do not take (an fp64 module; bf16
+    parameters, hence bf16 offsets and logits; box reference points) runs the default path
+    instead of raising."""
+    from instaorder_amd import MSDeformAttn
+    torch.manual_seed(1)
+    shapes = [(4, 4), (8, 8)]
+    ss = torch.tensor(shapes, dtype=torch.int64).cuda()
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    s = int(ss.prod(1).sum())
+    for dtype, last in ((torch.float64, 2), (torch.float32, 4)):
+        mod = MSDeformAttn(256, 2, 8, 4).cuda().to(dtype)
+        query, src = torch.randn(1, s, 256, device="cuda", dtype=dtype), torch.randn(1, s, 256, device="cuda", dtype=dtype)
+        ref = torch.rand(1, s, 2, last, device="cuda", dtype=dtype)
+        mod.fused_prologue = False
+        want = mod(query, ref, src, ss, lsi)
+        mod.fused_prologue = True
+        got = mod(query, ref, src, ss, lsi)
+        assert torch.equal(got, want)
 
 
 def test_forward_backward_capture_into_a_hip_graph(msda):

@@ -74,6 +74,33 @@ def test_position_embedding_sine_matches_reference_golden(key, kw, shape, masked
     assert float((got - torch.from_numpy(want)).abs().max()) < 1e-6
 
 
+def _encoder_case(key, dtype, device):
+    from instaorder_amd.encoder import MSDeformAttnTransformerEncoderOnly
+    ec, g = cases.make_encoder_case(key), load_golden("encoder_" + key)
+    enc = MSDeformAttnTransformerEncoderOnly(**ec["kwargs"]).to(dtype).to(device)
+    enc.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in ec["state_dict"].items()})   # strict: same keys
+    enc.eval()
+    srcs = [torch.from_numpy(x).to(dtype).to(device).requires_grad_(True) for x in ec["srcs"]]
+    pos = [torch.from_numpy(x).to(dtype).to(device) for x in ec["pos"]]
+    memory, shapes, lsi = enc(srcs, pos)
+    memory.backward(torch.from_numpy(ec["grad_memory"]).to(dtype).to(device))
+    return g, memory, shapes, lsi, srcs
+
+
+@pytest.mark.parametrize("key", sorted(cases.ENCODER_CASES))
+def test_encoder_stack_matches_reference_golden(key):
+    """Row f1: instaorder_amd.encoder.MSDeformAttnTransformerEncoderOnly (fp64, CPU path) against the output
+    and input gradients of the REFERENCE's class (pixel_decoder/msdeformattn.py:23-254, run by
+    tests/golden/make_golden.py) with the same seeded parameters -- loaded under the reference's state-dict
+    keys, adapters included."""
+    g, memory, shapes, lsi, srcs = _encoder_case(key, torch.float64, "cpu")
+    tol = 1e-12 if g["memory"].dtype == np.float64 else 1e-6          # 'heads8' is stored in fp32
+    assert (shapes.numpy() == g["shapes"]).all() and (lsi.numpy() == g["lsi"]).all()
+    assert rel_err(memory.detach().numpy(), g["memory"]) < tol
+    for i, x in enumerate(srcs):
+        assert rel_err(x.grad.numpy(), g["grad_src%d" % i]) < tol
+
+
 def test_shard_batch_covers_the_batch():
     from instaorder_amd.distributed import shard_batch
     for world in (1, 2, 3, 8):
