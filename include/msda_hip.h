@@ -80,11 +80,14 @@ int msda_forward_f64(const double *value, const int64_t *spatial_shapes,
  * aligned, contents irrelevant before and after; calls sharing one workspace must be ordered
  * on one stream); the plain variants take it from the stream-ordered pool.
  *
- * Level layout (read on the device; the reference checks none of it): rows of [0, spatial_size)
- * that belong to no level (spatial_size > sum H*W, or gaps in level_start_index) get zero
- * grad_value, as the reference's at::zeros_like gives them.  On the channels == 32 path a level
- * that is empty, leaves [0, spatial_size) -- where the reference reads and writes out of bounds --
- * or shares rows with another level makes the call return zeros in ALL THREE gradients (rc 0).
+ * Level layout (read on the device; the reference checks none of it).  Every level must be non-empty
+ * and lie inside [0, spatial_size); where one does not, the reference reads (forward) and writes
+ * (backward) out of bounds, and every entry point here returns ZEROS instead -- the output, or all
+ * three gradients -- with rc 0 and without touching memory outside its tensors.  Rows of
+ * [0, spatial_size) that belong to no level (spatial_size > sum H*W, or gaps in level_start_index)
+ * get zero grad_value, as the reference's at::zeros_like gives them.  Levels that share rows: the
+ * channels == 32 backward returns zeros in all three gradients; the other kernels compute (shared
+ * rows receive both levels' contributions).
  */
 size_t msda_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
                                      int num_levels, int num_query, int num_point);

@@ -59,6 +59,13 @@ inline int pick_group(int D) {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// spatial_size == 0 with queries: no level can lie inside the value tensor, every sample reads zero
+int zero_output(const char *who, void *out, size_t bytes, hipStream_t st) {
+  const hipError_t e = hipMemsetAsync(out, 0, bytes, st);
+  if (e != hipSuccess) return fail(MSDA_ERR_LAUNCH, "%s: hipMemsetAsync(output) failed: %s", who, hipGetErrorString(e));
+  return MSDA_OK;
+}
+
 template <typename T>
 int forward_generic(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc,
                     const T *aw, int N, int S, int M, int D, int L, int Lq, int P, T *out,
@@ -172,7 +179,7 @@ int forward_impl<float>(const float *value, const int64_t *shapes, const int64_t
   const size_t limit = (size_t)1 << 30;  // elements, i.e. 4 GiB of fp32
   const bool small = (size_t)N * S * M * D < limit && npairs * L * P * 2 < limit &&
                      npairs * D < limit;
-  if (D == 32 && small && aligned16(value) && aligned16(out)) {
+  if (D == 32 && S > 0 && small && aligned16(value) && aligned16(out)) {
     launch_forward_d32<float>(value, shapes, lsi, loc, aw, S, M, L, Lq, P, npairs, out, st);
     return check_launch("msda_forward_f32");
   }
@@ -444,6 +451,7 @@ int fused_forward(const char *who, const VT *value, const int64_t *shapes, const
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "%s: needs channels == 32, num_levels * num_point <= %d, aligned tensors of < 2^30 "
                 "elements (use the unfused entry points otherwise)", who, FWD_FUSED_MAX_LP);
+  if (S == 0) return zero_output(who, out, npairs * 32 * sizeof(VT), static_cast<hipStream_t>(stream));
   constexpr uint32_t GP = 64u / FwdLanes<VT>::LPG;
   const size_t lds = (size_t)4 * ((size_t)2 * GP * (size_t)(L * P + 1) * 16 + (((size_t)GP * L * P + 3) / 4) * 16);
   const uint32_t nq = (uint32_t)((size_t)N * Lq), nunits = ((nq + GP - 1u) / GP) * (uint32_t)M;
@@ -658,6 +666,7 @@ int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
       (reinterpret_cast<uintptr_t>(output) & 7u))
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "msda_forward_bf16: needs channels == 32, 8-byte aligned tensors of < 2^30 elements");
+  if (S == 0) return zero_output("msda_forward_bf16", output, npairs * 32 * sizeof(uint16_t), static_cast<hipStream_t>(stream));
   launch_forward_d32<bf16_t>(reinterpret_cast<const bf16_t *>(value), spatial_shapes,
                              level_start_index, sampling_loc, attn_weight, S, M, L, Lq, P, npairs,
                              reinterpret_cast<bf16_t *>(output), static_cast<hipStream_t>(stream));

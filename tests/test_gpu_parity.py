@@ -395,6 +395,49 @@ def test_levels_that_leave_the_value_tensor_or_overlap(msda):
     assert float((guard - 3.0).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("channels,dtype", [(32, torch.float32), (32, torch.bfloat16), (16, torch.float32),
+                                            (16, torch.float64)])
+def test_levels_outside_the_value_tensor_give_zeros_everywhere(msda, channels, dtype):
+    """A level that is empty or leaves [0, spatial_size) (the reference reads and writes out of bounds
+    there): every forward kernel returns a zero output, the generic backward (channels != 32, fp64) zero
+    gradients like the channels == 32 one, and nothing outside the tensors is touched; the intact layout
+    right after still computes."""
+    from instaorder_amd import synthetic
+    shapes = [(16, 16), (32, 32)]
+    inp = synthetic.make_inputs(2, shapes, heads=4, channels=channels, points=4, dist="uniform", seed=8,
+                                num_query=70, dtype=torch.float64)
+    fl = torch.float32 if dtype == torch.bfloat16 else dtype      # locations / weights of the bf16 variant are fp32
+    loc, aw = inp["sampling_locations"].to(fl).cuda(), inp["attention_weights"].to(fl).cuda()
+    go = inp["grad_output"].to(dtype).cuda()
+    guard = torch.full((1 << 20,), 3.0, device="cuda")
+    for lsi_bad, s_rows, ss in (([0, 256], 1000, shapes), ([-3, 256], 1280, shapes), ([0, 1 << 40], 1280, shapes),
+                                ([0, 256], 1280, [(16, 16), (0, 32)]), ([0, 256], 1280, [(16, 16), (1 << 33, 1)])):
+        v = inp["value"][:, :s_rows].contiguous().to(dtype).cuda()
+        args = (v, torch.tensor(ss).cuda(), torch.tensor(lsi_bad).cuda(), loc, aw)
+        out = msda.ms_deform_attn_forward(*args, 128)
+        grads = msda.ms_deform_attn_backward(*args, go, 128)
+        torch.cuda.synchronize()
+        assert float(out.float().abs().max()) == 0.0
+        for t in grads:
+            assert float(t.float().abs().max()) == 0.0
+    assert float((guard - 3.0).abs().max()) == 0.0
+    good = msda.ms_deform_attn_forward(inp["value"].to(dtype).cuda(), inp["spatial_shapes"].cuda(),
+                                       inp["level_start_index"].cuda(), loc, aw, 128)
+    assert float(good.float().abs().max()) > 0.0
+
+
+def test_forward_with_an_empty_value_tensor(msda):
+    """spatial_size == 0 with queries present: zeros, from every forward entry point."""
+    shapes = torch.tensor([[4, 4]]).cuda()
+    lsi = torch.tensor([0]).cuda()
+    for ch, dtype in ((32, torch.float32), (32, torch.bfloat16), (16, torch.float32)):
+        v = torch.zeros(2, 0, 4, ch, dtype=dtype, device="cuda")
+        loc = torch.rand(2, 9, 4, 1, 4, 2, device="cuda")
+        aw = torch.rand(2, 9, 4, 1, 4, device="cuda")
+        out = msda.ms_deform_attn_forward(v, shapes, lsi, loc, aw, 128)
+        assert out.shape == (2, 9, 4 * ch) and float(out.float().abs().max()) == 0.0
+
+
 def test_module_gpu_matches_reference_golden(msda):
     """MSDeformAttn module (row a11/f1) on the GPU: HIP op inside, fp32, vs the reference
     module's fp64 golden output and input gradients."""
