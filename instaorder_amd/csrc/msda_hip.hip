@@ -156,7 +156,8 @@ void launch_forward_d32(const VT *value, const int64_t *shapes, const int64_t *l
     const uint32_t nblk = (nunits + 3u) / 4u;
     hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT, false>), dim3(nblk), dim3(256), lds, st, value, shapes, lsi,
                        loc, aw, (const float *)nullptr, S, M, L, Lq, P, nq, nunits, nblk,
-                       aligned16(loc) && (reinterpret_cast<uintptr_t>(aw) & 7u) == 0, out);
+                       aligned16(loc) && (reinterpret_cast<uintptr_t>(aw) & 7u) == 0, fwd_div_magic((uint32_t)(L * P)),
+                       fwd_div_magic((uint32_t)P), fwd_div_magic32((uint32_t)M, nunits), fwd_div_magic_lq((uint32_t)Lq, nq, GP), out);
     return;
   }
   const uint32_t nblk = (uint32_t)((npairs + 31) / 32);
@@ -458,7 +459,8 @@ int fused_forward(const char *who, const VT *value, const int64_t *shapes, const
   const uint32_t nblk = (nunits + 3u) / 4u;
   hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT, true>), dim3(nblk), dim3(256), lds,
                      static_cast<hipStream_t>(stream), value, shapes, lsi, off, logits, refp, S, M, L, Lq, P,
-                     nq, nunits, nblk, false, out);
+                     nq, nunits, nblk, false, fwd_div_magic((uint32_t)(L * P)), fwd_div_magic((uint32_t)P),
+                     fwd_div_magic32((uint32_t)M, nunits), fwd_div_magic_lq((uint32_t)Lq, nq, GP), out);
   return check_launch(who);
 }
 
