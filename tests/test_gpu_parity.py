@@ -420,6 +420,18 @@ def test_levels_outside_the_value_tensor_give_zeros_everywhere(msda, channels, d
         assert float(out.float().abs().max()) == 0.0
         for t in grads:
             assert float(t.float().abs().max()) == 0.0
+        if channels == 32:                                        # the fused boundary runs the same kernels
+            from instaorder_amd import ext
+            refp = torch.rand(2, 70, 2, 2, device="cuda")
+            off = torch.randn(2, 70, 4, 2, 4, 2, device="cuda")
+            logits = torch.randn(2, 70, 4, 8, device="cuda")
+            fargs = (v, args[1], args[2], refp, off, logits)
+            fout = ext.ms_deform_attn_fused_forward(*fargs)
+            fgrads = ext.ms_deform_attn_fused_backward(*fargs, go)
+            torch.cuda.synchronize()
+            assert float(fout.float().abs().max()) == 0.0
+            for t in fgrads:
+                assert float(t.float().abs().max()) == 0.0
     assert float((guard - 3.0).abs().max()) == 0.0
     good = msda.ms_deform_attn_forward(inp["value"].to(dtype).cuda(), inp["spatial_shapes"].cuda(),
                                        inp["level_start_index"].cuda(), loc, aw, 128)
