@@ -438,6 +438,35 @@ def test_levels_outside_the_value_tensor_give_zeros_everywhere(msda, channels, d
     assert float(good.float().abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("channels,dtype", [(32, torch.float32), (16, torch.float64)])
+def test_non_finite_and_huge_locations_are_closed_samples(msda, oracle, channels, dtype):
+    """NaN, +-Inf and huge sampling locations fail the reference's range gate (cuh:293: every comparison
+    with NaN is false), so the sample contributes nothing and gets zero gradients; every kernel must
+    treat them the same way and never turn them into an address."""
+    from instaorder_amd import synthetic
+    shapes = [(20, 33), (9, 14), (40, 17)]
+    inp = synthetic.make_inputs(2, shapes, heads=4, channels=channels, points=4, dist="uniform", seed=21,
+                                num_query=160, dtype=dtype)
+    loc = inp["sampling_locations"]
+    flat = loc.view(-1, 2)
+    rng = np.random.RandomState(5)
+    bad = [float("nan"), float("inf"), float("-inf"), 1e30, -1e30, 3e38, -7.0, 9.0]
+    idx = rng.choice(flat.shape[0], size=400, replace=False)
+    for k, i in enumerate(idx):
+        flat[i, k % 2] = bad[k % len(bad)]               # x or y alone
+    for i in idx[:40]:
+        flat[i] = float("nan")                            # both
+    _oracle_check(msda, oracle, inp, FWD_TOL_F32 if dtype == torch.float32 else 1e-12,
+                  GRAD_TOL_F32 if dtype == torch.float32 else 1e-10)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    gv, gl, ga = msda.ms_deform_attn_backward(dev["value"], dev["spatial_shapes"], dev["level_start_index"],
+                                               dev["sampling_locations"], dev["attention_weights"],
+                                               dev["grad_output"], 128)
+    assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+    closed = torch.from_numpy(np.isin(np.arange(flat.shape[0]), idx)).cuda()
+    assert float(gl.view(-1, 2)[closed].abs().max()) == 0.0 and float(ga.view(-1)[closed].abs().max()) == 0.0
+
+
 def test_forward_with_an_empty_value_tensor(msda):
     """spatial_size == 0 with queries present: zeros, from every forward entry point."""
     shapes = torch.tensor([[4, 4]]).cuda()
