@@ -103,6 +103,37 @@ def test_generic_shapes_vs_oracle(msda, oracle, channels, heads, points, levels)
         _oracle_check(msda, oracle, inp, ftol, gtol)
 
 
+@pytest.mark.parametrize("heads,points,levels,queries", [
+    (1, 1, 1, 1), (8, 1, 3, 37), (16, 2, 8, 50), (3, 4, 9, 21), (2, 2, 5, 300), (5, 3, 1, 64), (8, 4, 8, 9)])
+def test_channels_32_shape_sweep_vs_oracle(msda, oracle, heads, points, levels, queries):
+    """channels == 32 at the corners of what the fast kernels take (1..4 points, 1..8 levels, one head, one
+    query) and just beyond (9 levels: generic backward), fp32 and bf16 storage."""
+    from instaorder_amd import synthetic
+    shapes = [(23, 40), (12, 20), (6, 10), (3, 5), (17, 17), (1, 9), (33, 2), (16, 16), (5, 31)][:levels]
+    inp = synthetic.make_inputs(2, shapes, heads=heads, channels=32, points=points, dist="uniform", seed=17,
+                                num_query=queries)
+    inp["sampling_locations"] = inp["sampling_locations"] * 1.3 - 0.15
+    inp = _off_lattice(inp)
+    _oracle_check(msda, oracle, inp, FWD_TOL_F32, GRAD_TOL_F32)
+    b = dict(inp)
+    b["value"] = inp["value"].bfloat16().float()
+    b["grad_output"] = inp["grad_output"].bfloat16().float()
+    n = lambda k: b[k].double().numpy() if b[k].is_floating_point() else b[k].numpy()
+    o_out = oracle.forward(n("value"), n("spatial_shapes"), n("level_start_index"), n("sampling_locations"),
+                           n("attention_weights"))
+    o_gv, o_gl, o_ga = oracle.backward(n("value"), n("spatial_shapes"), n("level_start_index"),
+                                       n("sampling_locations"), n("attention_weights"), n("grad_output"))
+    dev = {k: v.cuda() for k, v in b.items()}
+    args = (dev["value"].bfloat16(), dev["spatial_shapes"], dev["level_start_index"], dev["sampling_locations"],
+            dev["attention_weights"])
+    out = msda.ms_deform_attn_forward(*args, 128)
+    assert rel_err(out.float().cpu().numpy(), o_out) < BF16_TOL
+    if points <= 4 and levels <= 8:                              # the bf16 backward has no generic path
+        gv, gl, ga = (t.float().cpu().numpy() for t in
+                      msda.ms_deform_attn_backward(*args, dev["grad_output"].bfloat16(), 128))
+        assert rel_err(gv, o_gv) < GRAD_TOL_F32 and rel_err(gl, o_gl) < GRAD_TOL_F32 and rel_err(ga, o_ga) < GRAD_TOL_F32
+
+
 @pytest.mark.parametrize("channels", [30, 32, 64, 71])
 def test_gradcheck_like_reference(msda, channels):
     """ops/test.py:66-81: fp64 gradcheck of all three differentiable inputs."""
