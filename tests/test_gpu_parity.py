@@ -856,6 +856,10 @@ def test_fused_entry_points_match_unfused(msda, shapes, heads, points, num_query
 @pytest.mark.parametrize("shapes,heads,points,num_query,batch", [
     ([(8, 8), (16, 16), (32, 32)], 8, 4, None, 2),
     ([(7, 9), (5, 3)], 3, 3, 37, 3),
+    ([(9, 11), (6, 6), (12, 5), (3, 20)], 2, 4, 29, 2),          # L * P == 16, the fused forward's limit
+    ([(13, 7)], 1, 1, 1, 1),                                      # one level, one point, one head, one query
+    ([(4, 4), (5, 5), (6, 6), (7, 7), (8, 8), (3, 9), (9, 3), (2, 2)], 4, 2, 40, 2),      # 8 levels
+    ([(4, 4), (5, 5), (6, 6), (7, 7), (8, 8), (3, 9), (9, 3), (2, 2), (10, 4)], 2, 1, 33, 2),   # 9 levels: generic backward inside
 ])
 def test_fused_entry_points_vs_oracle(msda, oracle, shapes, heads, points, num_query, batch):
     """The fused entry points against the C ORACLE (not against the unfused HIP path): softmax and
