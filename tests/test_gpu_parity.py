@@ -498,6 +498,34 @@ def test_non_finite_and_huge_locations_are_closed_samples(msda, oracle, channels
     assert float(gl.view(-1, 2)[closed].abs().max()) == 0.0 and float(ga.view(-1)[closed].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("which", ["value", "sampling_locations", "attention_weights", "grad_output", "all"])
+def test_tensors_at_odd_addresses_vs_oracle(msda, oracle, which):
+    """Contiguous tensors that start 4 bytes into an allocation (views of a larger buffer): the 16-byte
+    kernels must not be chosen for them; results as for aligned tensors."""
+    from instaorder_amd import synthetic
+    shapes = [(12, 20), (6, 10), (24, 40)]
+    inp = synthetic.make_inputs(2, shapes, heads=8, channels=32, points=4, dist="uniform", seed=4, num_query=190)
+    inp = _off_lattice(inp)
+
+    def shifted(t):
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device="cuda")
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.is_contiguous() and v.data_ptr() % 16 == 4
+        return v
+
+    dev = {k: (shifted(v) if (which in (k, "all") and v.is_floating_point()) else v.cuda()) for k, v in inp.items()}
+    out, gv, gl, ga = _run(msda, dev["value"], dev["spatial_shapes"], dev["level_start_index"],
+                           dev["sampling_locations"], dev["attention_weights"], dev["grad_output"])
+    n = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    o_out = oracle.forward(n("value"), n("spatial_shapes"), n("level_start_index"), n("sampling_locations"),
+                           n("attention_weights"))
+    o_gv, o_gl, o_ga = oracle.backward(n("value"), n("spatial_shapes"), n("level_start_index"),
+                                       n("sampling_locations"), n("attention_weights"), n("grad_output"))
+    assert rel_err(out, o_out) < FWD_TOL_F32
+    assert rel_err(gv, o_gv) < GRAD_TOL_F32 and rel_err(gl, o_gl) < GRAD_TOL_F32 and rel_err(ga, o_ga) < GRAD_TOL_F32
+
+
 def test_forward_with_an_empty_value_tensor(msda):
     """spatial_size == 0 with queries present: zeros, from every forward entry point."""
     shapes = torch.tensor([[4, 4]]).cuda()
