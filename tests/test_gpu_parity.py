@@ -526,6 +526,41 @@ def test_tensors_at_odd_addresses_vs_oracle(msda, oracle, which):
     assert rel_err(gv, o_gv) < GRAD_TOL_F32 and rel_err(gl, o_gl) < GRAD_TOL_F32 and rel_err(ga, o_ga) < GRAD_TOL_F32
 
 
+def test_bf16_tensors_at_8_byte_addresses_vs_oracle(msda, oracle):
+    """bf16 value / grad_output that start 8 bytes into an allocation (the variant's minimum alignment):
+    the 8-byte kernels run and match; 2 bytes in is refused."""
+    from instaorder_amd import synthetic
+    shapes = [(12, 20), (6, 10), (24, 40)]
+    inp = synthetic.make_inputs(2, shapes, heads=8, channels=32, points=4, dist="uniform", seed=6, num_query=170)
+    inp = _off_lattice(inp)
+    inp["value"] = inp["value"].bfloat16().float()
+    inp["grad_output"] = inp["grad_output"].bfloat16().float()
+
+    def shifted(t, elems):
+        buf = torch.empty(t.numel() + elems, dtype=torch.bfloat16, device="cuda")
+        v = buf[elems:].view(t.shape)
+        v.copy_(t)
+        return v
+
+    dev = {k: v.cuda() for k, v in inp.items()}
+    args = (shifted(inp["value"], 4), dev["spatial_shapes"], dev["level_start_index"], dev["sampling_locations"],
+            dev["attention_weights"])
+    assert args[0].data_ptr() % 16 == 8
+    out = msda.ms_deform_attn_forward(*args, 128)
+    gv, gl, ga = msda.ms_deform_attn_backward(*args, shifted(inp["grad_output"], 4), 128)
+    n = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    o_out = oracle.forward(n("value"), n("spatial_shapes"), n("level_start_index"), n("sampling_locations"),
+                           n("attention_weights"))
+    o_gv, o_gl, o_ga = oracle.backward(n("value"), n("spatial_shapes"), n("level_start_index"),
+                                       n("sampling_locations"), n("attention_weights"), n("grad_output"))
+    c = lambda t: t.float().cpu().numpy()
+    assert rel_err(c(out), o_out) < BF16_TOL
+    assert rel_err(c(gv), o_gv) < GRAD_TOL_F32 and rel_err(c(gl), o_gl) < GRAD_TOL_F32 and rel_err(c(ga), o_ga) < GRAD_TOL_F32
+    with pytest.raises(RuntimeError):
+        msda.ms_deform_attn_forward(shifted(inp["value"], 1), *args[1:], 128)
+    torch.cuda.synchronize()
+
+
 def test_forward_with_an_empty_value_tensor(msda):
     """spatial_size == 0 with queries present: zeros, from every forward entry point."""
     shapes = torch.tensor([[4, 4]]).cuda()
