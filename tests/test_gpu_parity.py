@@ -561,6 +561,48 @@ def test_bf16_tensors_at_8_byte_addresses_vs_oracle(msda, oracle):
     torch.cuda.synchronize()
 
 
+def test_calls_from_several_host_threads_on_their_own_streams(msda):
+    """Four host threads, each on its own stream with its own inputs, call forward and backward at the same
+    time (the binding releases the GIL inside the library): every result equals the one the same inputs
+    give alone.  Covers the thread-local error text, the per-call workspace and work queue."""
+    import threading
+    from instaorder_amd import synthetic
+    shapes = [(16, 16), (32, 32), (8, 8)]
+    inputs, alone = [], []
+    for t in range(4):
+        inp = synthetic.make_inputs(2 + t, shapes, heads=8, channels=32, points=4, dist="model", seed=30 + t,
+                                    device="cuda")
+        args = tuple(inp[k] for k in ("value", "spatial_shapes", "level_start_index", "sampling_locations",
+                                      "attention_weights"))
+        inputs.append((args, inp["grad_output"]))
+        alone.append((msda.ms_deform_attn_forward(*args, 128), msda.ms_deform_attn_backward(*args, inp["grad_output"], 128)))
+    torch.cuda.synchronize()
+    got, errors = [None] * 4, []
+
+    def work(t):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    args, go = inputs[t]
+                    got[t] = (msda.ms_deform_attn_forward(*args, 128), msda.ms_deform_attn_backward(*args, go, 128))
+            st.synchronize()
+        except Exception as e:                                    # noqa: BLE001 - reported below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t in range(4):
+        assert torch.equal(got[t][0], alone[t][0])                # the forward is deterministic
+        for a, b in zip(got[t][1], alone[t][1]):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5   # list order varies: last bits only
+
+
 def test_forward_with_an_empty_value_tensor(msda):
     """spatial_size == 0 with queries present: zeros, from every forward entry point."""
     shapes = torch.tensor([[4, 4]]).cuda()
