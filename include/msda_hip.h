@@ -36,7 +36,8 @@ extern "C" {
 #define MSDA_ERR_INVALID_ARGUMENT 1
 #define MSDA_ERR_LAUNCH 2
 
-/* Library ABI version (bumped when a signature changes). */
+/* Library ABI version (bumped when a signature changes or an entry point is added; 4: msda_backward_bf16_gv16_ws,
+ * msda_backward_bf16_gv16_workspace_bytes, msda_backward_min_workspace_bytes; 3 had msda_backward_f32_noalloc). */
 int msda_abi_version(void);
 
 /* Thread-local text of the last error returned on this thread ("" if none). */
@@ -74,11 +75,16 @@ int msda_forward_f64(const double *value, const int64_t *spatial_shapes,
  * ms_deform_attn_cuda.cu:126); grad_sampling_loc and grad_attn_weight are fully written.
  *
  * channels == 32, num_point <= 4, num_levels <= 8 (every InstaFormer configuration) runs the
- * binned destination-tiled kernels, which sort the samples by destination tile in a workspace
- * of msda_backward_workspace_bytes(...) bytes; other shapes run the generic atomic kernels and
- * need none.  The *_ws variants take the workspace from the caller (any device memory, 4-byte
- * aligned, contents irrelevant before and after; calls sharing one workspace must be ordered
- * on one stream); the plain variants take it from the stream-ordered pool.
+ * binned destination-tiled kernels, which sort the samples by destination tile in a workspace;
+ * other shapes run the generic atomic kernels and need none (both queries then return 0).  The
+ * *_ws variants take the workspace from the caller (any device memory, 4-byte aligned, contents
+ * irrelevant before and after; calls sharing one workspace must be ordered on one stream); the
+ * plain variants take msda_backward_workspace_bytes(...) from the stream-ordered pool.
+ * Workspace size: msda_backward_workspace_bytes(...) holds the lists of the whole batch, the
+ * fastest (one pass of the kernels).  Images are independent, so a caller short of memory may
+ * pass any size from msda_backward_min_workspace_bytes(...) -- one image's lists -- upwards:
+ * the batch then goes through the workspace in groups of as many images as fit, one group after
+ * the other on the stream (same results; 2-4 % slower per halving at the encoder shapes).
  *
  * Level layout (read on the device; the reference checks none of it).  Every level must be non-empty
  * and lie inside [0, spatial_size); where one does not, the reference reads (forward) and writes
@@ -91,6 +97,8 @@ int msda_forward_f64(const double *value, const int64_t *spatial_shapes,
  */
 size_t msda_backward_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
                                      int num_levels, int num_query, int num_point);
+size_t msda_backward_min_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                         int num_levels, int num_query, int num_point);
 
 int msda_backward_f32(const float *value, const int64_t *spatial_shapes,
                       const int64_t *level_start_index, const float *sampling_loc,
@@ -113,10 +121,12 @@ int msda_backward_f32_ws(const float *value, const int64_t *spatial_shapes,
  * hipFree / pool allocation anywhere.  No counterpart in the reference (its launcher allocates
  * through ATen, src/cuda/ms_deform_attn_cuda.cu:126-128).  The sort-by-tile workspace is a
  * 64 MiB array built into the library's code object (each GPU the library runs on holds its copy
- * until the process ends); a problem whose msda_backward_workspace_bytes(...) exceeds
- * msda_backward_noalloc_max_workspace_bytes() -- more than about 970,000 (image, query, head,
- * level) quads, e.g. more than one 1024^2 image of the encoder shape -- is rejected with
- * MSDA_ERR_INVALID_ARGUMENT (use msda_backward_f32_ws).  Shapes off the channels == 32 fast path
+ * until the process ends); the batch goes through it in groups of as many images as fit, so any
+ * batch size is taken, and only a problem whose ONE image needs more --
+ * msda_backward_min_workspace_bytes(...) > msda_backward_noalloc_max_workspace_bytes(): more than
+ * about 970,000 (query, head, level) quads per image; the 1024^2 encoder shape has 516,096, the
+ * 1536^2 one 1,161,216 -- is rejected with MSDA_ERR_INVALID_ARGUMENT (use msda_backward_f32_ws).
+ * Shapes off the channels == 32 fast path
  * run the generic kernels, which need no workspace.  All calls on one GPU share that GPU's array:
  * calls that overlap on one GPU (different streams or threads) race; order them on one stream.
  */
@@ -141,9 +151,15 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
  * float/double only, src/cuda/ms_deform_attn_cuda.cu:69,139, and its caller forces fp32,
  * pixel_decoder/msdeformattn.py:435-441).  value / output / grad_output are bfloat16 bit
  * patterns (uint16_t); sampling locations, attention weights and ALL THREE gradients are fp32;
- * accumulation is fp32.  grad_value comes back in fp32 (algorithmic bytes 68.00 B/sample, not
- * 62.67).  Both need channels == 32 (backward also num_point <= 4, num_levels <= 8).  Same
- * kernels as the fp32 fast paths; msda_backward_bf16_ws as msda_backward_f32_ws.
+ * accumulation is fp32.  msda_backward_bf16[_ws] hand grad_value back in fp32 (algorithmic bytes
+ * 68.00 B/sample); msda_backward_bf16_gv16_ws hands it back in bfloat16 -- the tile that owns a
+ * row rounds its fp32 register sums once, at the store -- which is BASELINE.md's bf16 variant
+ * (62.67 B/sample) and what an autograd caller wants (value's dtype, no conversion pass).  Its
+ * workspace is msda_backward_bf16_gv16_workspace_bytes(...): the lists, plus -- small batches
+ * only, whose long lists are split over workgroups that add in fp32 -- an fp32 staging tensor
+ * of grad_value's shape; 16-byte aligned; smaller workspaces down to
+ * msda_backward_min_workspace_bytes(...) as above.  All need channels == 32 (backward also
+ * num_point <= 4, num_levels <= 8).  Same kernels as the fp32 fast paths.
  */
 int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                       const int64_t *level_start_index, const float *sampling_loc,
@@ -165,6 +181,17 @@ int msda_backward_bf16_ws(const uint16_t *value, const int64_t *spatial_shapes,
                           int num_query, int num_point, float *grad_value,
                           float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
                           size_t workspace_bytes, void *stream);
+
+size_t msda_backward_bf16_gv16_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                               int num_levels, int num_query, int num_point);
+
+int msda_backward_bf16_gv16_ws(const uint16_t *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start_index, const float *sampling_loc,
+                               const float *attn_weight, const uint16_t *grad_output, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels,
+                               int num_query, int num_point, uint16_t *grad_value,
+                               float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /*
  * Fused boundary (opt-in, fp32): the op together with its two

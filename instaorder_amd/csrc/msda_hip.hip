@@ -28,13 +28,14 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // Host side.
 // ---------------------------------------------------------------------------------------
-// An error some other library left on this thread (hipGetLastError is per thread and sticky until
-// read) must not be reported as a failed MSDA launch: every entry point passes through check_dims,
-// which clears it first.
-void clear_stale_error() { (void)hipGetLastError(); }
+// hipGetLastError is per thread and sticky until read.  An error some other library left pending on this thread
+// must neither be reported as a failed MSDA launch nor be consumed here (the application's own check would never
+// see it): every entry point notes what is pending when it is entered (check_dims), and a launch has failed when
+// the pending error afterwards is a different one.  Nothing here resets the thread's error state.
+thread_local hipError_t g_pending = hipSuccess;
 
 int check_dims(const char *who, int N, int S, int M, int D, int L, int Lq, int P) {
-  clear_stale_error();
+  g_pending = hipPeekAtLastError();
   if (N < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0)
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "%s: bad dimensions batch=%d spatial_size=%d num_heads=%d channels=%d "
@@ -44,8 +45,8 @@ int check_dims(const char *who, int N, int S, int M, int D, int L, int Lq, int P
 }
 
 int check_launch(const char *who) {
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess)
+  const hipError_t e = hipPeekAtLastError();
+  if (e != hipSuccess && e != g_pending)
     return fail(MSDA_ERR_LAUNCH, "%s: kernel launch failed: %s", who, hipGetErrorString(e));
   g_launches.fetch_add(1, std::memory_order_relaxed);
   return MSDA_OK;
@@ -245,28 +246,43 @@ bool binned_shape(int N, int S, int M, int D, int L, int Lq, int P) {
          npairs * L * binned::MAX_ENTRIES_PER_QUAD < ((size_t)1 << 32);         // 32-bit list positions
 }
 
-// uint32 words: counters[key_cap + 1] + work counter, list starts[key_cap + 1] + pad, descriptors[quads],
-// entries[16 * quads];
-// key_cap: one list per (image, head, tile), and a level has at most H*W tiles.
+// Workspace of one group of images, uint32 words: counters[key_cap + 1] + work counter, list starts[key_cap + 1] +
+// pad, descriptors[quads], entries[16 * quads]; key_cap: one list per (image, head, tile), and a level has at most
+// H*W tiles.  A batch may be taken in several groups of images, one after the other through the same workspace
+// (images are independent), so a caller short of memory can pass anything from one image's worth upwards.
 size_t binned_key_cap(int N, int S, int M) { return (size_t)N * M * S; }
-size_t binned_workspace_bytes(int N, int S, int M, int L, int Lq, int P) {
-  (void)P;
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Small batches: fewer than ~8 tiles per workgroup means the tile kernel runs as long as its longest list
+// (coarse-level tiles), so those lists are split over workgroups that ADD their partial sums with float atomics
+// into a zero-filled fp32 tensor: grad_value itself, or -- bf16 grad_value -- a staging tensor in the workspace.
+bool binned_split(int N, int S, int M) {
+  const size_t est_items = (size_t)N * M * (size_t)((S + binned::TP - 1) / binned::TP);
+  return est_items < (size_t)16 * num_cus();
+}
+size_t binned_lists_bytes(int N, int S, int M, int L, int Lq) {
   const size_t words = 2 * (binned_key_cap(N, S, M) + 2) +
                        (size_t)(1 + binned::MAX_ENTRIES_PER_QUAD) * N * Lq * M * L;
-  return (words * 4 + 255) & ~(size_t)255;
+  return align256(words * 4);
+}
+size_t binned_workspace_bytes(int N, int S, int M, int L, int Lq, int P, bool gv16 = false) {
+  (void)P;
+  size_t bytes = binned_lists_bytes(N, S, M, L, Lq);
+  if (gv16 && binned_split(N, S, M)) bytes += align256((size_t)N * S * M * 32 * sizeof(float));
+  return bytes;
+}
+// images per group: the most that fit the workspace (0: not even one)
+int binned_group(int N, int S, int M, int L, int Lq, int P, bool gv16, size_t workspace_bytes) {
+  for (int g = N; g >= 1; --g)
+    if (binned_workspace_bytes(g, S, M, L, Lq, P, gv16) <= workspace_bytes) return g;
+  return 0;
 }
 
-template <typename VT>
-int launch_backward_binned(const char *who, const VT *value, const int64_t *shapes,
-                           const int64_t *lsi, const float *loc, const float *aw,
-                           const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
-                           float *grad_value, float *grad_loc, float *grad_aw, void *workspace,
-                           size_t workspace_bytes, hipStream_t st) {
-  const size_t need = binned_workspace_bytes(N, S, M, L, Lq, P);
-  if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 3u))
-    return fail(MSDA_ERR_INVALID_ARGUMENT,
-                "%s: needs a 4-byte aligned device workspace of at least %zu bytes (got %zu)", who,
-                need, workspace ? workspace_bytes : (size_t)0);
+template <typename VT, typename GT>
+int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
+                        const int64_t *lsi, const float *loc, const float *aw,
+                        const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
+                        GT *grad_value, float *grad_loc, float *grad_aw, void *workspace, hipStream_t st) {
   const uint32_t key_cap = (uint32_t)binned_key_cap(N, S, M);
   uint32_t *counts = static_cast<uint32_t *>(workspace);
   uint32_t *work = counts + (size_t)key_cap + 1;
@@ -276,8 +292,9 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
   const uint32_t spi = (uint32_t)((size_t)Lq * M * L);          // quads per image
   const uint32_t bpi = (spi + binned::BIN_QB - 1) / binned::BIN_QB;
   const int cus = num_cus();
+  constexpr bool GV16 = sizeof(GT) == 2;
   hipLaunchKernelGGL(binned::msda_bwd_bin_zero_kernel, dim3(cus), dim3(256), 0, st, shapes, lsi, N, S, M, L,
-                     Lq, P, key_cap, counts, grad_value, grad_loc, grad_aw);
+                     Lq, P, key_cap, GV16 ? 3u : 4u, counts, static_cast<void *>(grad_value), grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   const uint64_t magic_ml = (((uint64_t)1 << 40) + (uint64_t)(M * L) - 1) / (uint64_t)(M * L);
   const uint64_t magic_l = (((uint64_t)1 << 40) + (uint64_t)L - 1) / (uint64_t)L;
@@ -292,27 +309,68 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
                      0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
                      entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
-  // Small batches: fewer than ~8 tiles per workgroup means the kernel runs as long as its longest
-  // list (coarse-level tiles), so those lists are split over workgroups that add their partial
-  // sums with float atomics into a zero-filled grad_value.
-  const size_t est_items = (size_t)N * M * (size_t)((S + binned::TP - 1) / binned::TP);
-  const int split_enable = est_items < (size_t)16 * cus ? 1 : 0;
+  const int split_enable = binned_split(N, S, M) ? 1 : 0;
+  const size_t gv_elems = (size_t)N * S * M * 32;
   if (split_enable) {
-    const hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * 32, st);
+    // every tile of this group adds to, or stores into, one zero-filled fp32 tensor
+    float *sums = GV16 ? reinterpret_cast<float *>(static_cast<char *>(workspace) + binned_lists_bytes(N, S, M, L, Lq))
+                       : reinterpret_cast<float *>(grad_value);
+    const hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * gv_elems, st);
     if (e != hipSuccess)
       return fail(MSDA_ERR_LAUNCH, "%s: hipMemsetAsync(grad_value) failed: %s", who, hipGetErrorString(e));
+    hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, float>), dim3(2 * cus), dim3(binned::NT), 0, st,
+                       grad_out, value, shapes, lsi, loc, aw, offs, entries, offs + (size_t)key_cap + 1, work,
+                       key_cap, N, S, M, L, P, 1, sums, sums, grad_loc, grad_aw);
+    if (int rc = check_launch(who)) return rc;
+    if (GV16) {
+      hipLaunchKernelGGL(binned::msda_bwd_round_kernel, dim3(2 * cus), dim3(256), 0, st, sums,
+                         reinterpret_cast<bf16_t *>(grad_value), shapes, lsi, N, S, M, L, key_cap,
+                         (uint64_t)(gv_elems / 4));
+      return check_launch(who);
+    }
+    return MSDA_OK;
   }
-  hipLaunchKernelGGL(binned::msda_bwd_binned_kernel<VT>, dim3(2 * cus), dim3(binned::NT), 0, st,
+  hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, GT>), dim3(2 * cus), dim3(binned::NT), 0, st,
                      grad_out, value, shapes, lsi, loc, aw, offs, entries, offs + (size_t)key_cap + 1, work,
-                     key_cap, N, S, M, L, P, split_enable, grad_value, grad_loc, grad_aw);
+                     key_cap, N, S, M, L, P, 0, grad_value, (float *)nullptr, grad_loc, grad_aw);
   return check_launch(who);
 }
 
+template <typename VT, typename GT>
+int launch_backward_binned(const char *who, const VT *value, const int64_t *shapes,
+                           const int64_t *lsi, const float *loc, const float *aw,
+                           const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
+                           GT *grad_value, float *grad_loc, float *grad_aw, void *workspace,
+                           size_t workspace_bytes, hipStream_t st) {
+  constexpr bool GV16 = sizeof(GT) == 2;
+  const uintptr_t amask = GV16 ? 15u : 3u;             // bf16 grad_value: an fp32 staging tensor may sit behind the lists
+  const int g = (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & amask))
+                    ? 0 : binned_group(N, S, M, L, Lq, P, GV16, workspace_bytes);
+  if (g == 0)
+    return fail(MSDA_ERR_INVALID_ARGUMENT,
+                "%s: needs a %d-byte aligned device workspace of at least %zu bytes (one image at a time; %zu for the "
+                "whole batch at once, the fastest), got %zu", who, (int)amask + 1, binned_workspace_bytes(1, S, M, L, Lq, P, GV16),
+                binned_workspace_bytes(N, S, M, L, Lq, P, GV16), workspace ? workspace_bytes : (size_t)0);
+  const size_t pairs_img = (size_t)Lq * M, samples_img = pairs_img * L * P, rows_img = (size_t)S * M * 32;
+  for (int n0 = 0; n0 < N; n0 += g) {
+    const int ng = N - n0 < g ? N - n0 : g;
+    if (int rc = launch_binned_group<VT, GT>(who, value + n0 * rows_img, shapes, lsi, loc + n0 * samples_img * 2,
+                                             aw + n0 * samples_img, grad_out + n0 * pairs_img * 32, ng, S, M, L,
+                                             Lq, P, grad_value + n0 * rows_img, grad_loc + n0 * samples_img * 2,
+                                             grad_aw + n0 * samples_img, workspace, st))
+      return rc;
+  }
+  return MSDA_OK;
+}
+
 // Which D == 32 backward: binned (default) or, with MSDA_BWD_IMPL=generic, the atomic kernel
-// (A/B measurements).
+// (A/B measurements).  Read once per process.
 int bwd_impl_choice() {
-  const char *e = getenv("MSDA_BWD_IMPL");
-  return (e && strcmp(e, "generic") == 0) ? 0 : 2;
+  static const int choice = [] {
+    const char *e = getenv("MSDA_BWD_IMPL");
+    return (e && strcmp(e, "generic") == 0) ? 0 : 2;
+  }();
+  return choice;
 }
 
 // Workspace from the device's stream-ordered pool when the caller brought none.
@@ -333,19 +391,19 @@ struct PoolWorkspace {
   }
 };
 
-template <typename VT>
+template <typename VT, typename GT>
 int backward_d32(const char *who, const VT *value, const int64_t *shapes, const int64_t *lsi,
                  const float *loc, const float *aw, const VT *grad_out, int N, int S, int M, int L,
-                 int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw, void *workspace,
+                 int Lq, int P, GT *grad_value, float *grad_loc, float *grad_aw, void *workspace,
                  size_t workspace_bytes, bool own_workspace, hipStream_t st) {
   if (!own_workspace)
-    return launch_backward_binned<VT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
-                                      grad_value, grad_loc, grad_aw, workspace, workspace_bytes, st);
+    return launch_backward_binned<VT, GT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
+                                          grad_value, grad_loc, grad_aw, workspace, workspace_bytes, st);
   PoolWorkspace pool(st);
-  const size_t need = binned_workspace_bytes(N, S, M, L, Lq, P);
+  const size_t need = binned_workspace_bytes(N, S, M, L, Lq, P, sizeof(GT) == 2);
   if (int rc = pool.get(who, need)) return rc;
-  return launch_backward_binned<VT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
-                                    grad_value, grad_loc, grad_aw, pool.ptr, need, st);
+  return launch_backward_binned<VT, GT>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
+                                        grad_value, grad_loc, grad_aw, pool.ptr, need, st);
 }
 
 int backward_f32(const char *who, const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -356,9 +414,9 @@ int backward_f32(const char *who, const float *value, const int64_t *shapes, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (binned_shape(N, S, M, D, L, Lq, P) && aligned16(value) && aligned16(grad_out) &&
       aligned16(grad_value) && aligned16(loc) && aligned16(grad_loc) && bwd_impl_choice() != 0)
-    return backward_d32<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
-                               grad_value, grad_loc, grad_aw, workspace, workspace_bytes,
-                               own_workspace, st);
+    return backward_d32<float, float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
+                                      grad_value, grad_loc, grad_aw, workspace, workspace_bytes,
+                                      own_workspace, st);
   return backward_atomic<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P,
                                 grad_value, grad_loc, grad_aw, st);
 }
@@ -404,40 +462,46 @@ int backward_f32_noalloc(const char *who, const float *value, const int64_t *sha
   if (!fast)   // the generic kernels use no scratch buffer at all (one hipMemsetAsync, no allocation)
     return backward_atomic<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P, grad_value,
                                   grad_loc, grad_aw, static_cast<hipStream_t>(stream));
-  const size_t need = binned_workspace_bytes(N, S, M, L, Lq, P);
+  // the batch goes through the built-in array in groups of as many images as fit (images are independent)
+  const size_t need = binned_workspace_bytes(1, S, M, L, Lq, P);
   if (need > NOALLOC_SCRATCH_BYTES)
     return fail(MSDA_ERR_INVALID_ARGUMENT,
-                "%s: this problem needs %zu bytes of sort workspace, more than the %zu-byte built-in scratch "
-                "buffer (about 970,000 (image, query, head, level) quads); use msda_backward_f32_ws with a "
-                "caller-provided workspace", who, need, NOALLOC_SCRATCH_BYTES);
+                "%s: one image of this problem needs %zu bytes of sort workspace, more than the %zu-byte built-in "
+                "scratch buffer (about 970,000 (query, head, level) quads per image); use msda_backward_f32_ws with "
+                "a caller-provided workspace", who, need, NOALLOC_SCRATCH_BYTES);
   void *scratch = nullptr;
   if (int rc = noalloc_scratch(who, &scratch)) return rc;
-  return launch_backward_binned<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P, grad_value,
-                                       grad_loc, grad_aw, scratch, NOALLOC_SCRATCH_BYTES,
-                                       static_cast<hipStream_t>(stream));
+  return launch_backward_binned<float, float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
+                                              grad_value, grad_loc, grad_aw, scratch, NOALLOC_SCRATCH_BYTES,
+                                              static_cast<hipStream_t>(stream));
 }
 
+// `grad_value` is fp32, or (gv16) bfloat16 bit patterns
 int backward_bf16(const char *who, const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                   const float *loc, const float *aw, const uint16_t *grad_out, int N, int S, int M,
-                  int D, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_aw,
+                  int D, int L, int Lq, int P, void *grad_value, bool gv16, float *grad_loc, float *grad_aw,
                   void *workspace, size_t workspace_bytes, bool own_workspace, void *stream) {
   if (int rc = check_dims(who, N, S, M, D, L, Lq, P)) return rc;
   if (!binned_shape(N, S, M, D, L, Lq, P) || (reinterpret_cast<uintptr_t>(value) & 7u) ||
-      (reinterpret_cast<uintptr_t>(grad_out) & 7u) || !aligned16(grad_value) || !aligned16(loc) ||
-      !aligned16(grad_loc))
+      (reinterpret_cast<uintptr_t>(grad_out) & 7u) || (reinterpret_cast<uintptr_t>(grad_value) & (gv16 ? 7u : 15u)) ||
+      !aligned16(loc) || !aligned16(grad_loc))
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "%s: needs channels == 32, num_point <= %d, num_levels <= %d, a non-empty batch and "
                 "aligned tensors of < 2^30 elements",
                 who, binned::MAXP, binned::MAXL);
-  return backward_d32<bf16_t>(who, reinterpret_cast<const bf16_t *>(value), shapes, lsi, loc, aw,
-                              reinterpret_cast<const bf16_t *>(grad_out), N, S, M, L, Lq, P,
-                              grad_value, grad_loc, grad_aw, workspace, workspace_bytes,
-                              own_workspace, static_cast<hipStream_t>(stream));
+  const bf16_t *v = reinterpret_cast<const bf16_t *>(value), *go = reinterpret_cast<const bf16_t *>(grad_out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gv16)
+    return backward_d32<bf16_t, bf16_t>(who, v, shapes, lsi, loc, aw, go, N, S, M, L, Lq, P,
+                                        static_cast<bf16_t *>(grad_value), grad_loc, grad_aw, workspace,
+                                        workspace_bytes, own_workspace, st);
+  return backward_d32<bf16_t, float>(who, v, shapes, lsi, loc, aw, go, N, S, M, L, Lq, P,
+                                     static_cast<float *>(grad_value), grad_loc, grad_aw, workspace,
+                                     workspace_bytes, own_workspace, st);
 }
 
 
 // ---- row f3: fused boundary (fp32) ----
-size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 template <typename VT>
 int fused_forward(const char *who, const VT *value, const int64_t *shapes, const int64_t *lsi, const float *refp,
@@ -499,7 +563,7 @@ int fused_backward(const char *who, bool bf16, const void *value, const int64_t 
     if (int rc = check_launch(who)) return rc;
   }
   const int rc = bf16 ? backward_bf16(who, static_cast<const uint16_t *>(value), shapes, lsi, loc, aw,
-                                      static_cast<const uint16_t *>(grad_out), N, S, M, D, L, Lq, P, grad_value,
+                                      static_cast<const uint16_t *>(grad_out), N, S, M, D, L, Lq, P, grad_value, false,
                                       grad_off, grad_logits, inner, inner_bytes, false, stream)
                       : backward_f32(who, static_cast<const float *>(value), shapes, lsi, loc, aw,
                                      static_cast<const float *>(grad_out), N, S, M, D, L, Lq, P, grad_value,
@@ -580,7 +644,7 @@ int msda_debug_phase_cycles(unsigned long long *out16) {
 }
 #endif
 
-int msda_abi_version(void) { return 3; }
+int msda_abi_version(void) { return 4; }
 
 const char *msda_last_error(void) { return g_err; }
 
@@ -683,7 +747,7 @@ int msda_backward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                        float *grad_attn_weight, void *stream) {
   return backward_bf16("msda_backward_bf16", value, spatial_shapes, level_start_index, sampling_loc,
                        attn_weight, grad_output, batch, spatial_size, num_heads, channels,
-                       num_levels, num_query, num_point, grad_value, grad_sampling_loc,
+                       num_levels, num_query, num_point, grad_value, false, grad_sampling_loc,
                        grad_attn_weight, nullptr, 0, true, stream);
 }
 
@@ -696,8 +760,36 @@ int msda_backward_bf16_ws(const uint16_t *value, const int64_t *spatial_shapes,
                           void *stream) {
   return backward_bf16("msda_backward_bf16_ws", value, spatial_shapes, level_start_index,
                        sampling_loc, attn_weight, grad_output, batch, spatial_size, num_heads,
-                       channels, num_levels, num_query, num_point, grad_value, grad_sampling_loc,
+                       channels, num_levels, num_query, num_point, grad_value, false, grad_sampling_loc,
                        grad_attn_weight, workspace, workspace_bytes, false, stream);
+}
+
+int msda_backward_bf16_gv16_ws(const uint16_t *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start_index, const float *sampling_loc,
+                               const float *attn_weight, const uint16_t *grad_output, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels,
+                               int num_query, int num_point, uint16_t *grad_value, float *grad_sampling_loc,
+                               float *grad_attn_weight, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+  return backward_bf16("msda_backward_bf16_gv16_ws", value, spatial_shapes, level_start_index,
+                       sampling_loc, attn_weight, grad_output, batch, spatial_size, num_heads,
+                       channels, num_levels, num_query, num_point, grad_value, true, grad_sampling_loc,
+                       grad_attn_weight, workspace, workspace_bytes, false, stream);
+}
+
+size_t msda_backward_bf16_gv16_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                               int num_levels, int num_query, int num_point) {
+  if (!binned_shape(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point)) return 0;
+  return binned_workspace_bytes(batch, spatial_size, num_heads, num_levels, num_query, num_point, true);
+}
+
+size_t msda_backward_min_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                         int num_levels, int num_query, int num_point) {
+  if (!binned_shape(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point) ||
+      bwd_impl_choice() == 0)
+    return 0;
+  // one image at a time, with room for the fp32 staging tensor a bf16 grad_value of one image needs
+  return binned_workspace_bytes(1, spatial_size, num_heads, num_levels, num_query, num_point, true);
 }
 
 int msda_backward_f64(const double *value, const int64_t *spatial_shapes,

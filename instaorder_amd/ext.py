@@ -46,8 +46,11 @@ def _load():
     for suffix in ("f32", "bf16"):
         b = getattr(lib, "msda_backward_%s_ws" % suffix)
         b.argtypes, b.restype = ws_args, _I
-    lib.msda_backward_workspace_bytes.argtypes = [_I] * 7
-    lib.msda_backward_workspace_bytes.restype = ctypes.c_size_t
+    for q in ("msda_backward_workspace_bytes", "msda_backward_min_workspace_bytes",
+              "msda_backward_bf16_gv16_workspace_bytes"):
+        getattr(lib, q).argtypes = [_I] * 7
+        getattr(lib, q).restype = ctypes.c_size_t
+    lib.msda_backward_bf16_gv16_ws.argtypes, lib.msda_backward_bf16_gv16_ws.restype = ws_args, _I
     lib.msda_last_error.restype = ctypes.c_char_p
     lib.msda_launch_count.restype = ctypes.c_uint64
     lib.msda_abi_version.restype = _I
@@ -58,10 +61,22 @@ def _load():
         b.argtypes, b.restype = [_P] * 7 + [_I] * 7 + [_P] * 4 + [ctypes.c_size_t, _P], _I
     lib.msda_fused_backward_workspace_bytes.argtypes = [_I] * 7
     lib.msda_fused_backward_workspace_bytes.restype = ctypes.c_size_t
-    if lib.msda_abi_version() != 3:
+    if lib.msda_abi_version() != 4:
         raise RuntimeError("libmsda_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+# Upper limit (bytes) on the backward's sort workspace, or None: the lists of the whole batch at once (the
+# fastest).  With a limit the library takes the batch through the workspace in groups of as many images as fit
+# (include/msda_hip.h); never less than one image's worth is allocated.
+workspace_limit_bytes = None
+
+
+def _workspace_bytes(lib, full, dims):
+    if workspace_limit_bytes is None or full <= workspace_limit_bytes:
+        return full
+    return max(int(workspace_limit_bytes), int(lib.msda_backward_min_workspace_bytes(*dims)))
 
 
 def launch_count():
@@ -152,10 +167,9 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         raise RuntimeError("grad_output must be [N, Lq, M*D] with value's dtype")
     lib = _load()
     with torch.cuda.device(value.device):
-        # fully written by the library; fp32 also for a bf16 value (the kernels accumulate and
-        # hand back grad_value in fp32 -- see include/msda_hip.h)
-        grad_value = torch.empty(value.shape, device=value.device,
-                                 dtype=torch.float32 if value.dtype == torch.bfloat16 else value.dtype)
+        # fully written by the library, in value's dtype (bf16 variant: the fp32 sums of a row are rounded
+        # once, by the tile that owns the row -- msda_backward_bf16_gv16_ws, include/msda_hip.h)
+        grad_value = torch.empty_like(value)
         grad_sampling_loc = torch.empty_like(sampling_loc)
         grad_attn_weight = torch.empty_like(attn_weight)
         stream = torch.cuda.current_stream().cuda_stream
@@ -168,10 +182,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         else:
             # the sort-by-destination-tile workspace comes from torch's caching allocator
             # (the library's own entry points without _ws use the HIP stream-ordered pool)
-            nbytes = int(lib.msda_backward_workspace_bytes(n, s, m, d, nl, lq, npt))
+            bf16 = value.dtype == torch.bfloat16
+            query = lib.msda_backward_bf16_gv16_workspace_bytes if bf16 else lib.msda_backward_workspace_bytes
+            nbytes = _workspace_bytes(lib, int(query(n, s, m, d, nl, lq, npt)), (n, s, m, d, nl, lq, npt))
             workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=value.device)
-            rc = getattr(lib, "msda_backward_%s_ws" % _SUFFIX[value.dtype])(
-                *args, workspace.data_ptr(), nbytes, stream)
+            entry = lib.msda_backward_bf16_gv16_ws if bf16 else lib.msda_backward_f32_ws
+            rc = entry(*args, workspace.data_ptr(), nbytes, stream)
     if rc != 0:
         _raise(lib, "ms_deform_attn_backward")
     return [grad_value, grad_sampling_loc, grad_attn_weight]

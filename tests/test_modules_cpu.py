@@ -129,6 +129,24 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     assert r2["unit"] == "imgs/s" and r2["value"] > 0
 
 
+def test_train_bench_self_launches_or_refuses():
+    """`python train_bench.py --gpus 2` without a launcher starts its own two ranks (gloo here); with a
+    WORLD_SIZE that contradicts --gpus it refuses instead of reporting one rank as two."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="2")
+    common = ["--cpu", "--image", "64", "--global-batch", "4", "--steps", "1", "--warmup", "0"]
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "train_bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    r = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["value"] > 0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "train_bench.py"), "--gpus", "4"] + common,
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
 def test_bench_self_launches_two_ranks_gloo():
     """`python bench.py --gpus 2` with no launcher in the environment starts its own two ranks
     (fresh child processes under torch.distributed.run).  On this GPU-less host the ranks run the

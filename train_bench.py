@@ -18,6 +18,8 @@ Prints one JSON line on rank 0 (imgs/s over the whole job)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,8 +43,26 @@ def build_encoder(levels=3, freeze_base=True, seed=0):
     return enc
 
 
+def launch_ranks(args):
+    """`python train_bench.py --gpus N` without a launcher: start the N ranks as children of this
+    process (which has imported torch but made no GPU call) and hand back their exit code --
+    the single-node form of the reference's detectron2 `launch(main, num_gpus, ...)`
+    (train_net.py:404-414)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def run(args):
-    world, rank, local = D.init()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "unset")))
+    world, rank, local = D.init("gloo" if args.cpu else None)
     device = torch.device("cuda", local) if torch.cuda.is_available() and not args.cpu else torch.device("cpu")
     shapes = synthetic.encoder_shapes(args.image)
     enc = build_encoder(len(shapes), args.freeze_base).to(device)
