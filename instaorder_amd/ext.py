@@ -155,7 +155,13 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                             grad_output, im2col_step):
-    """-> [grad_value, grad_sampling_loc, grad_attn_weight].  Reference: ms_deform_attn.h:46-66."""
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight].  Reference: ms_deform_attn.h:46-66.
+
+    Level layouts the reference never builds (include/msda_hip.h): a level that is empty or leaves
+    [0, spatial_size) gives zeros in all three gradients from every kernel; levels that SHARE rows give zeros
+    from the channels == 32 kernels (which own whole rows) but are computed -- shared rows receive both levels'
+    contributions, as in the reference -- by the generic kernels (other channel counts, fp64) and by every
+    forward.  grad_value has value's dtype (a bf16 value: the fp32 sums rounded once)."""
     if not value.is_cuda:
         raise RuntimeError("Not implemented on the CPU")        # ms_deform_attn.h:65
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),

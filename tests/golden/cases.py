@@ -185,6 +185,11 @@ ENCODER_CASES = {
     "heads8": dict(kwargs=dict(d_model=256, nhead=8, num_encoder_layers=2, dim_feedforward=128, dropout=0.0,
                                num_feature_levels=3, enc_n_points=4, use_adapters=False),
                    shapes=[(2, 3), (4, 5), (8, 8)], batch=1, seed=502),          # 32 channels per head: the HIP fast path
+    # the reference's depth (6 layers, adapters on) at the encoder shape of a 128^2 image (strides 32/16/8)
+    "six_layers": dict(kwargs=dict(d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=128, dropout=0.0,
+                                   num_feature_levels=3, enc_n_points=4, use_adapters=True, adapter_dim=16,
+                                   adapter_scale=0.1),
+                       shapes=[(4, 4), (8, 8), (16, 16)], batch=1, seed=503),
 }
 
 

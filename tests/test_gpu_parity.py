@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL_F32 = 1e-5
 GRAD_TOL_F32 = 1e-4
+BF16_TOL = 1e-2       # north-star tolerance of the bf16 variant (BASELINE.md section 2)
+GV16_TOL = 4e-3       # grad_value of the bf16 variant: the fp32 sums rounded ONCE to bf16 (half an ulp = 2^-9 of an element)
 
 
 @pytest.fixture(scope="module")
@@ -63,9 +65,6 @@ def test_golden_f32(msda, name):
     assert rel_err(gv, g["grad_value"]) < GRAD_TOL_F32
     assert rel_err(gl, g["grad_loc"]) < GRAD_TOL_F32
     assert rel_err(ga, g["grad_aw"]) < GRAD_TOL_F32
-
-
-GV16_TOL_ = 4e-3      # see GV16_TOL below
 
 
 def _oracle_check(msda, oracle, inp, fwd_tol, grad_tol):
@@ -134,7 +133,7 @@ def test_channels_32_shape_sweep_vs_oracle(msda, oracle, heads, points, levels, 
     if points <= 4 and levels <= 8:                              # the bf16 backward has no generic path
         gv, gl, ga = (t.float().cpu().numpy() for t in
                       msda.ms_deform_attn_backward(*args, dev["grad_output"].bfloat16(), 128))
-        assert rel_err(gv, o_gv) < GV16_TOL_ and rel_err(gl, o_gl) < GRAD_TOL_F32 and rel_err(ga, o_ga) < GRAD_TOL_F32
+        assert rel_err(gv, o_gv) < GV16_TOL and rel_err(gl, o_gl) < GRAD_TOL_F32 and rel_err(ga, o_ga) < GRAD_TOL_F32
 
 
 @pytest.mark.parametrize("channels", [30, 32, 64, 71])
@@ -321,6 +320,44 @@ def test_full_size_properties(msda, image, batch, dist):
     assert float((gv.double() - gv64).abs().max()) < GRAD_TOL_F32 * float(gv64.abs().max())
 
 
+@pytest.mark.parametrize("image,batch", [(1024, 32)])
+def test_full_size_properties_bf16(msda, image, batch):
+    """BASELINE.json configs[2] at its own batch (bs 32 @1024^2, bf16 value / output / grad_output / grad_value):
+    size-independent properties that survive the bf16 roundings of the two row outputs -- the adjoint identity
+    <grad_out, F(v)> = <F^T(grad_out), v> (rounding errors of 2^-9 per element average out over 1.8e8 terms),
+    sum_s aw_s * grad_aw_s = <grad_out, out> per (image, query, head) to the bf16 tolerance, zero upstream gradient
+    -> zero gradients, and agreement of grad_sampling_loc / grad_attn_weight (fp32 outputs) with the fp32 kernels
+    run on the same rounded inputs."""
+    from instaorder_amd import synthetic
+    inp = synthetic.make_inputs(batch, synthetic.encoder_shapes(image), dist="model", seed=4, device="cuda")
+    ss, lsi, loc, aw = inp["spatial_shapes"], inp["level_start_index"], inp["sampling_locations"], inp["attention_weights"]
+    v, go = inp["value"].bfloat16(), inp["grad_output"].bfloat16()
+    out = msda.ms_deform_attn_forward(v, ss, lsi, loc, aw, 128)
+    gv, gl, ga = msda.ms_deform_attn_backward(v, ss, lsi, loc, aw, go, 128)
+    assert out.dtype == torch.bfloat16 and gv.dtype == torch.bfloat16
+    for t in (out, gv, gl, ga):
+        assert torch.isfinite(t).all()
+    lhs = float((go.double() * out.double()).sum())
+    rhs = float((gv.double() * v.double()).sum())
+    norm = float((go.double() * out.double()).abs().sum())
+    assert abs(lhs - rhs) < 1e-4 * norm
+    m, d = v.shape[2], v.shape[3]
+    per_pair = (go.view(batch, -1, m, d).double() * out.view(batch, -1, m, d).double()).sum(-1)
+    from_ga = (aw.double() * ga.double()).sum((-1, -2))
+    assert float((per_pair - from_ga).abs().max()) < BF16_TOL * float(per_pair.abs().max())
+    del per_pair, from_ga
+    # the fp32 kernels on the same (rounded) inputs: the two fp32 gradients agree to rounding, the rows to bf16
+    out32 = msda.ms_deform_attn_forward(v.float(), ss, lsi, loc, aw, 128)
+    gv32, gl32, ga32 = msda.ms_deform_attn_backward(v.float(), ss, lsi, loc, aw, go.float(), 128)
+    assert float((gl - gl32).abs().max()) < GRAD_TOL_F32 * float(gl32.abs().max())
+    assert float((ga - ga32).abs().max()) < GRAD_TOL_F32 * float(ga32.abs().max())
+    assert float((gv.float() - gv32).abs().max()) < GV16_TOL * float(gv32.abs().max())
+    assert float((out.float() - out32).abs().max()) < GV16_TOL * float(out32.abs().max())
+    del out32, gv32, gl32, ga32
+    gv0, gl0, ga0 = msda.ms_deform_attn_backward(v, ss, lsi, loc, aw, torch.zeros_like(go), 128)
+    assert float(gv0.float().abs().max()) == 0.0 and float(gl0.abs().max()) == 0.0 and float(ga0.abs().max()) == 0.0
+
+
 def test_full_size_image_vs_oracle(msda, oracle):
     """One image at 1024^2 (2.06 M samples), model-like locations, against the C oracle."""
     from instaorder_amd import synthetic
@@ -398,7 +435,7 @@ def test_levels_that_do_not_cover_every_row(msda, oracle, dtype):
     gv, gl, ga = (t.float().cpu().numpy() for t in
                   msda.ms_deform_attn_backward(*args, dev["grad_output"].to(dtype), 128))
     assert rel_err(out, o_out) < (FWD_TOL_F32 if dtype == torch.float32 else 1e-2)
-    assert rel_err(gv, want_gv) < (GRAD_TOL_F32 if dtype == torch.float32 else GV16_TOL_)
+    assert rel_err(gv, want_gv) < (GRAD_TOL_F32 if dtype == torch.float32 else GV16_TOL)
     assert rel_err(gl, o_gl) < GRAD_TOL_F32
     assert rel_err(ga, o_ga) < GRAD_TOL_F32
     covered = np.zeros(s_new, dtype=bool)
@@ -408,25 +445,55 @@ def test_levels_that_do_not_cover_every_row(msda, oracle, dtype):
 
 
 def test_levels_that_leave_the_value_tensor_or_overlap(msda):
-    """spatial_size < sum(H*W) (the reference would read and write out of bounds) or two levels
-    sharing rows: the channels == 32 backward returns zeros in all three gradients instead of
-    uninitialised memory, and touches nothing outside its tensors."""
+    """Layouts the reference would read / write out of bounds on (a level past spatial_size, a negative start) or
+    sharing rows: the channels == 32 backward returns zeros in all three gradients instead of uninitialised
+    memory.  Called through the C ABI with the three outputs carved out of ONE sentinel-filled buffer, so a write
+    next to any of them shows.  Levels that share rows are the one layout whose result depends on the kernel: the
+    forward and the generic backward (channels != 32, fp64) compute them (shared rows receive both levels'
+    contributions, as in the reference), the channels == 32 backward -- which owns whole rows -- returns zeros."""
     from instaorder_amd import synthetic
+    lib, ctypes = _abi()
     shapes = [(16, 16), (32, 32)]
     inp = synthetic.make_inputs(2, shapes, heads=4, channels=32, points=4, dist="uniform", seed=3,
                                 num_query=90, device="cuda")
     v, ss, loc, aw, go = (inp[k] for k in ("value", "spatial_shapes", "sampling_locations",
                                            "attention_weights", "grad_output"))
-    guard = torch.full((v.numel() + 4096,), 3.0, device="cuda")       # outputs carved out of guarded memory
+    pad = 4096
+    stream = torch.cuda.current_stream().cuda_stream
     for lsi, s_rows in ((torch.tensor([0, 256]), 1000),                # too few rows for level 1
                         (torch.tensor([0, 100]), 1280),                # level 1 starts inside level 0
                         (torch.tensor([-3, 256]), 1280)):              # negative start
         vv = v[:, :s_rows].contiguous()
-        gvs, gls, gas = msda.ms_deform_attn_backward(vv, ss, lsi.cuda(), loc, aw, go, 128)
+        sizes = (vv.numel(), loc.numel(), aw.numel())
+        buf = torch.full((sum(sizes) + 4 * pad,), 3.0, device="cuda")
+        starts = (pad, 2 * pad + sizes[0], 3 * pad + sizes[0] + sizes[1])
+        outs = [buf[a:a + k] for a, k in zip(starts, sizes)]
+        for o in outs:
+            o.fill_(7.0)
+        n, s_, m, d = vv.shape
+        need = int(lib.msda_backward_workspace_bytes(n, s_, m, d, 2, loc.shape[1], 4))
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        lsi_d = lsi.cuda()
+        rc = lib.msda_backward_f32_ws(vv.data_ptr(), ss.data_ptr(), lsi_d.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                                      go.data_ptr(), n, s_, m, d, 2, loc.shape[1], 4, outs[0].data_ptr(),
+                                      outs[1].data_ptr(), outs[2].data_ptr(), ws.data_ptr(), need, stream)
+        assert rc == 0, lib.msda_last_error()
         torch.cuda.synchronize()
-        for t in (gvs, gls, gas):
-            assert float(t.abs().max()) == 0.0
-    assert float((guard - 3.0).abs().max()) == 0.0
+        for o in outs:
+            assert float(o.abs().max()) == 0.0
+        guard = torch.ones_like(buf, dtype=torch.bool)
+        for a, k in zip(starts, sizes):
+            guard[a:a + k] = False
+        assert float((buf[guard] - 3.0).abs().max()) == 0.0, "a write outside the three gradients"
+    # shared rows: the forward (and the generic kernels) compute, the channels == 32 backward returns zeros
+    lsi_d = torch.tensor([0, 100]).cuda()
+    out = msda.ms_deform_attn_forward(v, ss, lsi_d, loc, aw, 128)
+    assert float(out.abs().max()) > 0.0
+    g16 = synthetic.make_inputs(2, shapes, heads=4, channels=16, points=4, dist="uniform", seed=3, num_query=90,
+                                device="cuda")
+    gv16c, _, _ = msda.ms_deform_attn_backward(g16["value"], ss, lsi_d, g16["sampling_locations"],
+                                               g16["attention_weights"], g16["grad_output"], 128)
+    assert float(gv16c.abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("channels,dtype", [(32, torch.float32), (32, torch.bfloat16), (16, torch.float32),
@@ -445,6 +512,7 @@ def test_levels_outside_the_value_tensor_give_zeros_everywhere(msda, channels, d
     go = inp["grad_output"].to(dtype).cuda()
     guard = torch.full((1 << 20,), 3.0, device="cuda")
     for lsi_bad, s_rows, ss in (([0, 256], 1000, shapes), ([-3, 256], 1280, shapes), ([0, 1 << 40], 1280, shapes),
+                                ([0, (1 << 63) - 1], 1280, shapes),      # start + H*W would wrap around int64
                                 ([0, 256], 1280, [(16, 16), (0, 32)]), ([0, 256], 1280, [(16, 16), (1 << 33, 1)])):
         v = inp["value"][:, :s_rows].contiguous().to(dtype).cuda()
         args = (v, torch.tensor(ss).cuda(), torch.tensor(lsi_bad).cuda(), loc, aw)
@@ -558,7 +626,7 @@ def test_bf16_tensors_at_8_byte_addresses_vs_oracle(msda, oracle):
                                        n("sampling_locations"), n("attention_weights"), n("grad_output"))
     c = lambda t: t.float().cpu().numpy()
     assert rel_err(c(out), o_out) < BF16_TOL
-    assert rel_err(c(gv), o_gv) < GV16_TOL_ and rel_err(c(gl), o_gl) < GRAD_TOL_F32 and rel_err(c(ga), o_ga) < GRAD_TOL_F32
+    assert rel_err(c(gv), o_gv) < GV16_TOL and rel_err(c(gl), o_gl) < GRAD_TOL_F32 and rel_err(c(ga), o_ga) < GRAD_TOL_F32
     with pytest.raises(RuntimeError):
         msda.ms_deform_attn_forward(shifted(inp["value"], 1), *args[1:], 128)
     torch.cuda.synchronize()
@@ -731,11 +799,9 @@ def test_encoder_stack_gpu_matches_reference_golden(msda, key):
         assert rel_err(x.grad.cpu().numpy(), g["grad_src%d" % i]) < 1e-4
 
 
-BF16_TOL = 1e-2       # north-star tolerance of the bf16 variant (BASELINE.md section 2)
-GV16_TOL = 4e-3       # grad_value of the bf16 variant: the fp32 sums rounded ONCE to bf16 (half an ulp = 2^-9 of an element)
 
 
-@pytest.mark.parametrize("dist,image,batch", [("model", 256, 3), ("uniform", 128, 2), ("model", 1024, 1)])
+@pytest.mark.parametrize("dist,image,batch", [("model", 256, 3), ("uniform", 128, 2), ("model", 1024, 1), ("model", 1024, 3)])
 def test_bf16_variant_vs_oracle(msda, oracle, dist, image, batch):
     """bf16 value / output / grad_output, fp32 locations, weights, accumulation and gradients,
     against the fp64 oracle run on the bf16-ROUNDED inputs."""
