@@ -8,9 +8,10 @@ state-dict keys match), the reference's
       mask2former/modeling/transformer_decoder/position_encoding.py:12-56
 
 Levels are passed LOW-RES FIRST, as MSDeformAttnPixelDecoder does (msdeformattn.py:440).
-Parity: MSDeformAttn itself is pinned by tests/golden/module_msdeformattn.npz; the stack above
-it cannot be imported from the reference here (it imports detectron2 at module scope), so the
-stack's parity is unpinned and its tests check structure, shapes and gradient flow."""
+Parity: pinned.  MSDeformAttn by tests/golden/module_msdeformattn.npz; the stack by
+tests/golden/encoder_{small,heads8,six_layers}.npz and position_encoding.npz -- outputs and input gradients of the
+REFERENCE's own classes, which tests/golden/make_golden.py imports with name-only placeholders for the detectron2
+symbols their module merely imports (nothing the encoder classes execute comes from a placeholder)."""
 import copy
 import math
 

@@ -7,9 +7,10 @@ names (``input_proj``, ``transformer``, ``pe_layer``, ``mask_features``, ``adapt
 
 Everything here is stock PyTorch (MIOpen convolutions, hipBLASLt); only the encoder's sampling op is
 ours.  detectron2's ``ShapeSpec`` / ``Conv2d`` / ``get_norm`` / registry are replaced by the few
-lines they amount to for this module.  Parity unpinned: detectron2 is not installable here, so the
-reference class cannot be imported to produce golden outputs; the tests check shapes, dtype
-behaviour, state-dict keys and that GPU tensors go through the HIP kernels."""
+lines they amount to for this module.  Parity: the encoder inside is pinned (encoder.py); the convolution /
+GroupNorm / FPN glue around it is unpinned -- the reference class EXECUTES detectron2's Conv2d and get_norm,
+which are not installable here, and a stand-in for them would pin nothing -- so its tests check shapes, dtype
+behaviour, state-dict keys and the GPU (HIP kernels) against the CPU path."""
 import math
 
 import torch

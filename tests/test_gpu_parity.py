@@ -783,6 +783,47 @@ def test_training_step_harness_gpu(msda, monkeypatch, freeze_base, bwd_calls):
     assert abs(losses["cuda"] - losses["cpu"]) <= 1e-4 * abs(losses["cpu"])
 
 
+def test_config_c1_cpu_forward_512_beside_the_hip_path(msda, oracle):
+    """BASELINE.json configs[0] on the GPU box: the CPU forward of one synthetic 512^2 image (levels 16^2/32^2/64^2,
+    S = 5376) -- the reference's MODEL.DEVICE=cpu behaviour, where its module falls back to
+    ms_deform_attn_core_pytorch (ops/modules/ms_deform_attn.py:119-121) -- through the op's PyTorch path and through
+    the 6-layer encoder stack on host cores, against the C oracle (op) and against the HIP path on the same weights
+    and inputs (stack)."""
+    import time
+    from instaorder_amd import ext, synthetic, ms_deform_attn_core_pytorch
+    from instaorder_amd.encoder import MSDeformAttnTransformerEncoderOnly, PositionEmbeddingSine
+    shapes = synthetic.encoder_shapes(512)
+    inp = synthetic.make_inputs(1, shapes, dist="model", seed=3)
+    t0 = time.perf_counter()
+    out = ms_deform_attn_core_pytorch(inp["value"], inp["spatial_shapes"], inp["sampling_locations"],
+                                      inp["attention_weights"])
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    n = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    ref = oracle.forward(n("value"), n("spatial_shapes"), n("level_start_index"), n("sampling_locations"),
+                         n("attention_weights"))
+    assert rel_err(out.numpy(), ref) < FWD_TOL_F32
+    hip = msda.ms_deform_attn_forward(*(inp[k].cuda() for k in ("value", "spatial_shapes", "level_start_index",
+                                                                "sampling_locations", "attention_weights")), 128)
+    assert rel_err(hip.cpu().numpy(), ref) < FWD_TOL_F32
+    torch.manual_seed(0)
+    enc = MSDeformAttnTransformerEncoderOnly(d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024,
+                                             dropout=0.0, num_feature_levels=3, enc_n_points=4, use_adapters=True)
+    enc.eval()
+    pe = PositionEmbeddingSine(128, normalize=True)
+    srcs = [torch.randn(1, 256, h, w) for h, w in shapes]
+    before = ext.launch_count()
+    with torch.no_grad():
+        mem_cpu, _, _ = enc(srcs, [pe(x) for x in srcs])
+        assert ext.launch_count() == before                 # the CPU path never reaches the extension
+        enc_gpu = enc.cuda()
+        mem_gpu, _, _ = enc_gpu([x.cuda() for x in srcs], [pe(x.cuda()) for x in srcs])
+    torch.cuda.synchronize()
+    assert ext.launch_count() >= before + 6
+    assert tuple(mem_cpu.shape) == (1, 5376, 256)
+    assert rel_err(mem_gpu.cpu().numpy(), mem_cpu.numpy()) < 1e-4
+    print("C1 op on the CPU path: %.1f ms" % cpu_ms)
+
+
 @pytest.mark.parametrize("key", sorted(cases.ENCODER_CASES))
 def test_encoder_stack_gpu_matches_reference_golden(msda, key):
     """Row f1 on the GPU: the encoder stack with the HIP op inside every layer (fp32; 'heads8' has 32
