@@ -144,6 +144,18 @@ int fwd_impl_choice() {
   return (e && strcmp(e, "plain") == 0) ? 0 : 1;
 }
 
+// Unit order of the queries-by-head forward: regions of 2^6 runs, runs fastest inside a region (C3: fp32 1.399 ->
+// 1.385 ms, bf16 1.011 -> 0.99 ms against heads fastest = 0; 2^2 ... 2^10 measured, profiles/r03/experiments).
+// MSDA_FWD_REGION_LOG2 overrides it for A/B runs; read once per process.
+uint32_t fwd_region_log2() {
+  static const uint32_t v = [] {
+    const char *e = getenv("MSDA_FWD_REGION_LOG2");
+    const int r = e ? atoi(e) : 6;
+    return (uint32_t)(r < 0 ? 0 : (r > 20 ? 20 : r));
+  }();
+  return v;
+}
+
 template <typename VT>
 void launch_forward_d32(const VT *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                         const float *aw, int S, int M, int L, int Lq, int P, size_t npairs, VT *out,
@@ -158,7 +170,8 @@ void launch_forward_d32(const VT *value, const int64_t *shapes, const int64_t *l
     hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT, false>), dim3(nblk), dim3(256), lds, st, value, shapes, lsi,
                        loc, aw, (const float *)nullptr, S, M, L, Lq, P, nq, nunits, nblk,
                        aligned16(loc) && (reinterpret_cast<uintptr_t>(aw) & 7u) == 0, fwd_div_magic((uint32_t)(L * P)),
-                       fwd_div_magic((uint32_t)P), fwd_div_magic32((uint32_t)M, nunits), fwd_div_magic_lq((uint32_t)Lq, nq, GP), out);
+                       fwd_div_magic((uint32_t)P), fwd_div_magic32((uint32_t)M, nunits), fwd_div_magic_lq((uint32_t)Lq, nq, GP),
+                       fwd_region_log2(), out);
     return;
   }
   const uint32_t nblk = (uint32_t)((npairs + 31) / 32);
@@ -524,7 +537,7 @@ int fused_forward(const char *who, const VT *value, const int64_t *shapes, const
   hipLaunchKernelGGL((msda_fwd_d32_qh_kernel<VT, true>), dim3(nblk), dim3(256), lds,
                      static_cast<hipStream_t>(stream), value, shapes, lsi, off, logits, refp, S, M, L, Lq, P,
                      nq, nunits, nblk, false, fwd_div_magic((uint32_t)(L * P)), fwd_div_magic((uint32_t)P),
-                     fwd_div_magic32((uint32_t)M, nunits), fwd_div_magic_lq((uint32_t)Lq, nq, GP), out);
+                     fwd_div_magic32((uint32_t)M, nunits), fwd_div_magic_lq((uint32_t)Lq, nq, GP), fwd_region_log2(), out);
   return check_launch(who);
 }
 
