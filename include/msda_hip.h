@@ -158,7 +158,8 @@ int msda_backward_f64(const double *value, const int64_t *spatial_shapes,
  * workspace is msda_backward_bf16_gv16_workspace_bytes(...): the lists, plus -- small batches
  * only, whose long lists are split over workgroups that add in fp32 -- an fp32 staging tensor
  * of grad_value's shape; 16-byte aligned; smaller workspaces down to
- * msda_backward_min_workspace_bytes(...) as above.  All need channels == 32 (backward also
+ * msda_backward_min_workspace_bytes(...) as above (a group of images whose staging tensor does
+ * not fit behind its lists runs unsplit: same results, the long lists are not shared out).  All need channels == 32 (backward also
  * num_point <= 4, num_levels <= 8).  Same kernels as the fp32 fast paths.
  */
 int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,

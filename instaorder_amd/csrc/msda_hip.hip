@@ -284,18 +284,25 @@ size_t binned_workspace_bytes(int N, int S, int M, int L, int Lq, int P, bool gv
   if (gv16 && binned_split(N, S, M)) bytes += align256((size_t)N * S * M * 32 * sizeof(float));
   return bytes;
 }
-// images per group: the most that fit the workspace (0: not even one)
-int binned_group(int N, int S, int M, int L, int Lq, int P, bool gv16, size_t workspace_bytes) {
+// images per group: the most whose LISTS fit the workspace (0: not even one).  Whether a group of a bf16-grad_value
+// call also gets its fp32 staging tensor -- i.e. may split its long lists -- is decided group by group
+// (binned_may_split): the last group of a batch can be smaller than the others, small enough to want the split mode
+// that the groups before it did not, and must not take its staging tensor for granted.
+int binned_group(int N, int S, int M, int L, int Lq, size_t workspace_bytes) {
   for (int g = N; g >= 1; --g)
-    if (binned_workspace_bytes(g, S, M, L, Lq, P, gv16) <= workspace_bytes) return g;
+    if (binned_lists_bytes(g, S, M, L, Lq) <= workspace_bytes) return g;
   return 0;
+}
+bool binned_may_split(int N, int S, int M, int L, int Lq, int P, bool gv16, size_t workspace_bytes) {
+  return binned_split(N, S, M) && (!gv16 || binned_workspace_bytes(N, S, M, L, Lq, P, true) <= workspace_bytes);
 }
 
 template <typename VT, typename GT>
 int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
                         const int64_t *lsi, const float *loc, const float *aw,
                         const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
-                        GT *grad_value, float *grad_loc, float *grad_aw, void *workspace, hipStream_t st) {
+                        GT *grad_value, float *grad_loc, float *grad_aw, void *workspace, size_t workspace_bytes,
+                        hipStream_t st) {
   const uint32_t key_cap = (uint32_t)binned_key_cap(N, S, M);
   uint32_t *counts = static_cast<uint32_t *>(workspace);
   uint32_t *work = counts + (size_t)key_cap + 1;
@@ -322,7 +329,7 @@ int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
                      0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
                      entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
-  const int split_enable = binned_split(N, S, M) ? 1 : 0;
+  const int split_enable = binned_may_split(N, S, M, L, Lq, P, sizeof(GT) == 2, workspace_bytes) ? 1 : 0;
   const size_t gv_elems = (size_t)N * S * M * 32;
   if (split_enable) {
     // every tile of this group adds to, or stores into, one zero-filled fp32 tensor
@@ -358,11 +365,11 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
   constexpr bool GV16 = sizeof(GT) == 2;
   const uintptr_t amask = GV16 ? 15u : 3u;             // bf16 grad_value: an fp32 staging tensor may sit behind the lists
   const int g = (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & amask))
-                    ? 0 : binned_group(N, S, M, L, Lq, P, GV16, workspace_bytes);
+                    ? 0 : binned_group(N, S, M, L, Lq, workspace_bytes);
   if (g == 0)
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "%s: needs a %d-byte aligned device workspace of at least %zu bytes (one image at a time; %zu for the "
-                "whole batch at once, the fastest), got %zu", who, (int)amask + 1, binned_workspace_bytes(1, S, M, L, Lq, P, GV16),
+                "whole batch at once, the fastest), got %zu", who, (int)amask + 1, binned_lists_bytes(1, S, M, L, Lq),
                 binned_workspace_bytes(N, S, M, L, Lq, P, GV16), workspace ? workspace_bytes : (size_t)0);
   const size_t pairs_img = (size_t)Lq * M, samples_img = pairs_img * L * P, rows_img = (size_t)S * M * 32;
   for (int n0 = 0; n0 < N; n0 += g) {
@@ -370,7 +377,7 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
     if (int rc = launch_binned_group<VT, GT>(who, value + n0 * rows_img, shapes, lsi, loc + n0 * samples_img * 2,
                                              aw + n0 * samples_img, grad_out + n0 * pairs_img * 32, ng, S, M, L,
                                              Lq, P, grad_value + n0 * rows_img, grad_loc + n0 * samples_img * 2,
-                                             grad_aw + n0 * samples_img, workspace, st))
+                                             grad_aw + n0 * samples_img, workspace, workspace_bytes, st))
       return rc;
   }
   return MSDA_OK;

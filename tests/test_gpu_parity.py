@@ -1104,6 +1104,45 @@ def test_c_abi_bf16_grad_value_in_bf16_and_in_fp32(msda, oracle, image, batch):
         assert bool((diff <= 2.0 ** -8 * gv32.abs() + 1e-5 * gv32.abs().max()).all())
 
 
+def test_bf16_grad_value_last_group_smaller_than_the_others(msda, oracle):
+    """A batch taken through a caller's workspace in groups whose LAST group is small enough to want the split
+    mode (long lists cut into parts that add into an fp32 staging tensor behind the lists) while the workspace was
+    sized for the lists of the larger groups only: that group must run unsplit, not write a staging tensor the
+    workspace has no room for.  8 images at 1024^2 with 64 queries: groups of 7 + 1; one image's staging tensor
+    (22 MB) is larger than the seven images' lists (10 MB).  The workspace sits between sentinels."""
+    from instaorder_amd import synthetic
+    lib, ctypes = _abi()
+    inp = synthetic.make_inputs(8, synthetic.encoder_shapes(1024), dist="uniform", seed=11, num_query=64)
+    inp["value"] = inp["value"].bfloat16().float()
+    inp["grad_output"] = inp["grad_output"].bfloat16().float()
+    nn = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    o_gv, o_gl, o_ga = oracle.backward(nn("value"), nn("spatial_shapes"), nn("level_start_index"),
+                                       nn("sampling_locations"), nn("attention_weights"), nn("grad_output"))
+    dev = {k: t.cuda() for k, t in inp.items()}
+    v, go = dev["value"].bfloat16(), dev["grad_output"].bfloat16()
+    ss, lsi, loc, aw = dev["spatial_shapes"], dev["level_start_index"], dev["sampling_locations"], dev["attention_weights"]
+    n, s, m, d = v.shape
+    nl, lq, p = ss.shape[0], loc.shape[1], loc.shape[4]
+    seven = int(lib.msda_backward_workspace_bytes(7, s, m, d, nl, lq, p))          # the lists of seven images
+    one16 = int(lib.msda_backward_bf16_gv16_workspace_bytes(1, s, m, d, nl, lq, p))  # one image: lists + staging
+    assert int(lib.msda_backward_workspace_bytes(8, s, m, d, nl, lq, p)) > seven and one16 > seven
+    guard = 1 << 20
+    buf = torch.full((guard + seven + one16 + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    base = buf.data_ptr() + guard
+    base += (-base) % 256
+    off0 = base - buf.data_ptr()
+    gv = torch.full(v.shape, 7.0, device="cuda").bfloat16()
+    gl, ga = torch.full_like(loc, 7.0), torch.full_like(aw, 7.0)
+    rc = lib.msda_backward_bf16_gv16_ws(v.data_ptr(), ss.data_ptr(), lsi.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                                        go.data_ptr(), n, s, m, d, nl, lq, p, gv.data_ptr(), gl.data_ptr(),
+                                        ga.data_ptr(), base, seven, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.msda_last_error()
+    torch.cuda.synchronize()
+    assert bool((buf[:off0] == 0x5A).all()) and bool((buf[off0 + seven:] == 0x5A).all()), "wrote outside the workspace"
+    assert rel_err(gv.float().cpu().numpy(), o_gv) < GV16_TOL
+    assert rel_err(gl.cpu().numpy(), o_gl) < GRAD_TOL_F32 and rel_err(ga.cpu().numpy(), o_ga) < GRAD_TOL_F32
+
+
 def test_backward_run_to_run_agreement(msda):
     """No float atomics on the D == 32 path, but the order of a tile's list (and with it the
     order of the sums) is not fixed: two runs agree to rounding, nothing more is promised."""
