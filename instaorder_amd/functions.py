@@ -32,8 +32,8 @@ class MSDeformAttnFunction(Function):
         grad_value, grad_sampling_loc, grad_attn_weight = ext.ms_deform_attn_backward(
             value, shapes, level_start, sampling_locations, attention_weights,
             grad_output.contiguous(), ctx.im2col_step)
-        # (bf16 variant: the library returns grad_value in fp32; autograd wants value's dtype)
-        return grad_value.to(value.dtype), None, None, grad_sampling_loc, grad_attn_weight, None
+        # grad_value already has value's dtype (bf16 variant: rounded once by the tile kernel, no conversion pass)
+        return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
 
 
 class MSDeformAttnFusedFunction(Function):
