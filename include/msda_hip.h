@@ -37,7 +37,8 @@ extern "C" {
 #define MSDA_ERR_LAUNCH 2
 
 /* Library ABI version (bumped when a signature changes or an entry point is added; 4: msda_backward_bf16_gv16_ws,
- * msda_backward_bf16_gv16_workspace_bytes, msda_backward_min_workspace_bytes; 3 had msda_backward_f32_noalloc). */
+ * msda_backward_bf16_gv16_workspace_bytes, msda_backward_min_workspace_bytes; 3 had msda_backward_f32_noalloc;
+ * 5 adds msda_backward_compact_workspace_bytes and takes short workspaces in rounds). */
 int msda_abi_version(void);
 
 /* Thread-local text of the last error returned on this thread ("" if none). */
@@ -80,11 +81,16 @@ int msda_forward_f64(const double *value, const int64_t *spatial_shapes,
  * *_ws variants take the workspace from the caller (any device memory, 4-byte aligned, contents
  * irrelevant before and after; calls sharing one workspace must be ordered on one stream); the
  * plain variants take msda_backward_workspace_bytes(...) from the stream-ordered pool.
- * Workspace size: msda_backward_workspace_bytes(...) holds the lists of the whole batch, the
- * fastest (one pass of the kernels).  Images are independent, so a caller short of memory may
- * pass any size from msda_backward_min_workspace_bytes(...) -- one image's lists -- upwards:
- * the batch then goes through the workspace in groups of as many images as fit, one group after
- * the other on the stream (same results; 2-4 % slower per halving at the encoder shapes).
+ * Workspace size: msda_backward_workspace_bytes(...) holds the lists of the whole batch at their
+ * worst case (16 entries per (query, head, level); real locations fill 1.4 - 4.5), the fastest:
+ * one pass of the kernels.  A caller short of memory may pass any size from
+ * msda_backward_min_workspace_bytes(...) upwards; what is there is used in two ways, chosen by the
+ * library: the lists are written and consumed in several ROUNDS through a smaller entry region
+ * (as many rounds are launched as the worst case needs; a round that finds no lists left returns
+ * at once: with 5 or more entries per quad only the first does anything, and the others cost two
+ * empty launches each), and the batch is taken in groups of as many images as run in at most four
+ * rounds, one group after the other on the stream.  Same results.  The minimum is one image at one
+ * entry per quad (sixteen rounds): about a tenth of one image's worst case.
  *
  * Level layout (read on the device; the reference checks none of it).  Every level must be non-empty
  * and lie inside [0, spatial_size); where one does not, the reference reads (forward) and writes
@@ -99,6 +105,13 @@ size_t msda_backward_workspace_bytes(int batch, int spatial_size, int num_heads,
                                      int num_levels, int num_query, int num_point);
 size_t msda_backward_min_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
                                          int num_levels, int num_query, int num_point);
+/* A size in between, for callers that care about memory: four entries per quad for the whole batch (four rounds,
+ * of which model-like locations, 1.35 entries per quad, use the first).  Measured bs 32 at 1024^2: 0.37 GB instead
+ * of 1.17 GB, backward 2.90 instead of 2.89 ms; bs 2 at 1536^2: 0.498 instead of 0.487 ms (the empty rounds' six
+ * launches).  bf16_grad_value != 0: for msda_backward_bf16_gv16_ws (adds the fp32 staging tensor of a small
+ * batch). */
+size_t msda_backward_compact_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                             int num_levels, int num_query, int num_point, int bf16_grad_value);
 
 int msda_backward_f32(const float *value, const int64_t *spatial_shapes,
                       const int64_t *level_start_index, const float *sampling_loc,
@@ -121,11 +134,11 @@ int msda_backward_f32_ws(const float *value, const int64_t *spatial_shapes,
  * hipFree / pool allocation anywhere.  No counterpart in the reference (its launcher allocates
  * through ATen, src/cuda/ms_deform_attn_cuda.cu:126-128).  The sort-by-tile workspace is a
  * 64 MiB array built into the library's code object (each GPU the library runs on holds its copy
- * until the process ends); the batch goes through it in groups of as many images as fit, so any
+ * until the process ends); the batch goes through it in rounds and groups of images as through any
+ * short workspace (above: five 1024^2 images per group, one 1536^2 image in two rounds), so any
  * batch size is taken, and only a problem whose ONE image needs more --
- * msda_backward_min_workspace_bytes(...) > msda_backward_noalloc_max_workspace_bytes(): more than
- * about 970,000 (query, head, level) quads per image; the 1024^2 encoder shape has 516,096, the
- * 1536^2 one 1,161,216 -- is rejected with MSDA_ERR_INVALID_ARGUMENT (use msda_backward_f32_ws).
+ * msda_backward_min_workspace_bytes(...) > msda_backward_noalloc_max_workspace_bytes(): encoder
+ * shapes beyond about 3400^2 -- is rejected with MSDA_ERR_INVALID_ARGUMENT (use msda_backward_f32_ws).
  * Shapes off the channels == 32 fast path
  * run the generic kernels, which need no workspace.  All calls on one GPU share that GPU's array:
  * calls that overlap on one GPU (different streams or threads) race; order them on one stream.

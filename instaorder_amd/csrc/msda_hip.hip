@@ -259,12 +259,20 @@ bool binned_shape(int N, int S, int M, int D, int L, int Lq, int P) {
          npairs * L * binned::MAX_ENTRIES_PER_QUAD < ((size_t)1 << 32);         // 32-bit list positions
 }
 
-// Workspace of one group of images, uint32 words: counters[key_cap + 1] + work counter, list starts[key_cap + 1] +
-// pad, descriptors[quads], entries[16 * quads]; key_cap: one list per (image, head, tile), and a level has at most
-// H*W tiles.  A batch may be taken in several groups of images, one after the other through the same workspace
-// (images are independent), so a caller short of memory can pass anything from one image's worth upwards.
+// Workspace of one group of images, uint32 words: counters[key_cap + 1] + pad, list starts[key_cap + 1] + zero
+// word, control words, descriptors[quads], entries[e_cap]; key_cap: one list per (image, head, tile), and a level
+// has at most H*W tiles.  Two ways to live with less than the whole batch's worst case (16 entries per quad):
+//   * a batch may be taken in several groups of images, one after the other through the same workspace (images
+//     are independent);
+//   * a group's entry region may be smaller than 16 per quad: its lists are then written and consumed in several
+//     ROUNDS (binned.inc), as many as the worst case needs -- model-like locations fill 1.35 entries per quad,
+//     uniformly random ones 4.5, so with 5 or more per quad the rounds after the first find nothing to do.
 size_t binned_key_cap(int N, int S, int M) { return (size_t)N * M * S; }
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t binned_quads(int N, int M, int L, int Lq) { return (size_t)N * Lq * M * L; }
+size_t binned_fixed_words(int N, int S, int M, int L, int Lq) {
+  return 2 * (binned_key_cap(N, S, M) + 2) + binned::CTRL_WORDS + binned_quads(N, M, L, Lq);
+}
 
 // Small batches: fewer than ~8 tiles per workgroup means the tile kernel runs as long as its longest list
 // (coarse-level tiles), so those lists are split over workgroups that ADD their partial sums with float atomics
@@ -273,28 +281,64 @@ bool binned_split(int N, int S, int M) {
   const size_t est_items = (size_t)N * M * (size_t)((S + binned::TP - 1) / binned::TP);
   return est_items < (size_t)16 * num_cus();
 }
+size_t binned_staging_bytes(int N, int S, int M) { return align256((size_t)N * S * M * 32 * sizeof(float)); }
+// every list of the group at once: one round
 size_t binned_lists_bytes(int N, int S, int M, int L, int Lq) {
-  const size_t words = 2 * (binned_key_cap(N, S, M) + 2) +
-                       (size_t)(1 + binned::MAX_ENTRIES_PER_QUAD) * N * Lq * M * L;
-  return align256(words * 4);
+  return align256(4 * (binned_fixed_words(N, S, M, L, Lq) + binned::MAX_ENTRIES_PER_QUAD * binned_quads(N, M, L, Lq)));
 }
 size_t binned_workspace_bytes(int N, int S, int M, int L, int Lq, int P, bool gv16 = false) {
   (void)P;
   size_t bytes = binned_lists_bytes(N, S, M, L, Lq);
-  if (gv16 && binned_split(N, S, M)) bytes += align256((size_t)N * S * M * 32 * sizeof(float));
+  if (gv16 && binned_split(N, S, M)) bytes += binned_staging_bytes(N, S, M);
   return bytes;
 }
-// images per group: the most whose LISTS fit the workspace (0: not even one).  Whether a group of a bf16-grad_value
-// call also gets its fp32 staging tensor -- i.e. may split its long lists -- is decided group by group
-// (binned_may_split): the last group of a batch can be smaller than the others, small enough to want the split mode
-// that the groups before it did not, and must not take its staging tensor for granted.
-int binned_group(int N, int S, int M, int L, int Lq, size_t workspace_bytes) {
-  for (int g = N; g >= 1; --g)
-    if (binned_lists_bytes(g, S, M, L, Lq) <= workspace_bytes) return g;
-  return 0;
+// four entries per quad for the whole batch -- four rounds, of which model-like locations (1.35 entries per quad)
+// use the first; the other three cost two empty launches each: bs 32 at 1024^2 0.37 GB instead of 1.17 GB and
+// 2.90 instead of 2.89 ms, bs 2 at 1536^2 0.498 instead of 0.487 ms
+constexpr size_t COMPACT_ENTRIES_PER_QUAD = 4;
+size_t binned_compact_bytes(int N, int S, int M, int L, int Lq, bool gv16) {
+  size_t bytes = align256(4 * (binned_fixed_words(N, S, M, L, Lq) + COMPACT_ENTRIES_PER_QUAD * binned_quads(N, M, L, Lq) +
+                               4 * (size_t)Lq));
+  if (gv16 && binned_split(N, S, M)) bytes += binned_staging_bytes(N, S, M);
+  return bytes;
 }
-bool binned_may_split(int N, int S, int M, int L, int Lq, int P, bool gv16, size_t workspace_bytes) {
-  return binned_split(N, S, M) && (!gv16 || binned_workspace_bytes(N, S, M, L, Lq, P, true) <= workspace_bytes);
+// the least a group of ONE image can run in: one entry per quad plus the longest list there can be (a list holds
+// at most one entry per point of each of the image's queries) -- sixteen rounds
+size_t binned_min_bytes(int S, int M, int L, int Lq) {
+  return 4 * (binned_fixed_words(1, S, M, L, Lq) + binned_quads(1, M, L, Lq) + 4 * (size_t)Lq);
+}
+
+// Entry region and rounds of a group of n images in `bytes` of workspace; e_cap == 0: the group does not fit.
+// Rounds: a round that is not the last holds more than e_cap - 4 * Lq entries (the next list did not fit, and no
+// list is longer than 4 * Lq), and there are at most 16 per quad in all.
+struct BinnedRegion {
+  size_t e_cap = 0;
+  int rounds = 0;
+};
+BinnedRegion binned_region(int n, int S, int M, int L, int Lq, size_t bytes) {
+  BinnedRegion r;
+  const size_t words = bytes / 4, fixed = binned_fixed_words(n, S, M, L, Lq), quads = binned_quads(n, M, L, Lq);
+  const size_t full = binned::MAX_ENTRIES_PER_QUAD * quads, longest = 4 * (size_t)Lq;
+  if (words < fixed + quads + longest) return r;
+  const size_t avail = words - fixed;
+  if (avail >= full) {
+    r.e_cap = full;
+    r.rounds = 1;
+  } else {
+    r.e_cap = avail;
+    r.rounds = (int)((full + (avail - longest) - 1) / (avail - longest));     // <= 16: avail - longest >= quads
+  }
+  return r;
+}
+// Images per group (0: not even one fits): the most that need at most four rounds -- three of which are empty
+// launches for any real set of locations -- else one image at a time in as many rounds as it takes.
+constexpr int COMFORTABLE_ROUNDS = 4;
+int binned_group(int N, int S, int M, int L, int Lq, size_t workspace_bytes) {
+  for (int g = N; g >= 1; --g) {
+    const BinnedRegion r = binned_region(g, S, M, L, Lq, workspace_bytes);
+    if (r.e_cap && r.rounds <= COMFORTABLE_ROUNDS) return g;
+  }
+  return binned_region(1, S, M, L, Lq, workspace_bytes).e_cap ? 1 : 0;
 }
 
 template <typename VT, typename GT>
@@ -303,57 +347,86 @@ int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
                         const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
                         GT *grad_value, float *grad_loc, float *grad_aw, void *workspace, size_t workspace_bytes,
                         hipStream_t st) {
+  constexpr bool GV16 = sizeof(GT) == 2;
+  // Small batches split their long lists over workgroups that add into a zero-filled fp32 tensor: grad_value
+  // itself, or (bf16 grad_value) a staging tensor at the END of the workspace -- when there is room for it without
+  // costing the lists a round; a group that cannot have it runs unsplit (same results).
+  bool split = binned_split(N, S, M);
+  BinnedRegion reg = binned_region(N, S, M, L, Lq, workspace_bytes);
+  size_t staging_off = 0;
+  if (split && GV16) {
+    const size_t sb = binned_staging_bytes(N, S, M);
+    staging_off = workspace_bytes > sb ? (workspace_bytes - sb) & ~(size_t)255 : 0;
+    const BinnedRegion with = binned_region(N, S, M, L, Lq, staging_off);
+    if (staging_off && with.e_cap && with.rounds <= reg.rounds)
+      reg = with;
+    else
+      split = false;
+  }
+  if (reg.e_cap == 0)     // launch_backward_binned chose the group to fit
+    return fail(MSDA_ERR_INVALID_ARGUMENT, "%s: workspace of %zu bytes is too small for %d image(s)", who, workspace_bytes, N);
   const uint32_t key_cap = (uint32_t)binned_key_cap(N, S, M);
   uint32_t *counts = static_cast<uint32_t *>(workspace);
-  uint32_t *work = counts + (size_t)key_cap + 1;
   uint32_t *offs = counts + (size_t)key_cap + 2;
-  uint32_t *desc = offs + (size_t)key_cap + 2;
-  uint32_t *entries = desc + (size_t)N * Lq * M * L;
+  uint32_t *zero_word = offs + (size_t)key_cap + 1;
+  uint32_t *ctrl = zero_word + 1;
+  uint32_t *desc = ctrl + binned::CTRL_WORDS;
+  uint32_t *entries = desc + binned_quads(N, M, L, Lq);
   const uint32_t spi = (uint32_t)((size_t)Lq * M * L);          // quads per image
   const uint32_t bpi = (spi + binned::BIN_QB - 1) / binned::BIN_QB;
   const int cus = num_cus();
-  constexpr bool GV16 = sizeof(GT) == 2;
   hipLaunchKernelGGL(binned::msda_bwd_bin_zero_kernel, dim3(cus), dim3(256), 0, st, shapes, lsi, N, S, M, L,
                      Lq, P, key_cap, GV16 ? 3u : 4u, counts, static_cast<void *>(grad_value), grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   const uint64_t magic_ml = (((uint64_t)1 << 40) + (uint64_t)(M * L) - 1) / (uint64_t)(M * L);
   const uint64_t magic_l = (((uint64_t)1 << 40) + (uint64_t)L - 1) / (uint64_t)L;
-  hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<false>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
+  hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<0>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
+                     0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u, counts, desc,
                      entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, lsi, N, S, M, L,
-                     key_cap, counts, offs);
+                     key_cap, (uint32_t)reg.e_cap, reg.rounds, counts, offs);
   if (int rc = check_launch(who)) return rc;
-  hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<true>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, counts, desc,
-                     entries, grad_loc, grad_aw);
-  if (int rc = check_launch(who)) return rc;
-  const int split_enable = binned_may_split(N, S, M, L, Lq, P, sizeof(GT) == 2, workspace_bytes) ? 1 : 0;
   const size_t gv_elems = (size_t)N * S * M * 32;
-  if (split_enable) {
-    // every tile of this group adds to, or stores into, one zero-filled fp32 tensor
-    float *sums = GV16 ? reinterpret_cast<float *>(static_cast<char *>(workspace) + binned_lists_bytes(N, S, M, L, Lq))
-                       : reinterpret_cast<float *>(grad_value);
+  float *sums = nullptr;                               // split mode: what the parts of a tile's list add into
+  if (split) {
+    sums = GV16 ? reinterpret_cast<float *>(static_cast<char *>(workspace) + staging_off)
+                : reinterpret_cast<float *>(grad_value);
     const hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * gv_elems, st);
     if (e != hipSuccess)
       return fail(MSDA_ERR_LAUNCH, "%s: hipMemsetAsync(grad_value) failed: %s", who, hipGetErrorString(e));
-    hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, float>), dim3(2 * cus), dim3(binned::NT), 0, st,
-                       grad_out, value, shapes, lsi, loc, aw, offs, entries, offs + (size_t)key_cap + 1, work,
-                       key_cap, N, S, M, L, P, 1, sums, sums, grad_loc, grad_aw);
-    if (int rc = check_launch(who)) return rc;
-    if (GV16) {
-      hipLaunchKernelGGL(binned::msda_bwd_round_kernel, dim3(2 * cus), dim3(256), 0, st, sums,
-                         reinterpret_cast<bf16_t *>(grad_value), shapes, lsi, N, S, M, L, key_cap,
-                         (uint64_t)(gv_elems / 4));
-      return check_launch(who);
-    }
-    return MSDA_OK;
   }
-  hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, GT>), dim3(2 * cus), dim3(binned::NT), 0, st,
-                     grad_out, value, shapes, lsi, loc, aw, offs, entries, offs + (size_t)key_cap + 1, work,
-                     key_cap, N, S, M, L, P, 0, grad_value, (float *)nullptr, grad_loc, grad_aw);
-  return check_launch(who);
+  // one scatter pass + one tile-kernel pass per round (one round unless the caller's workspace is short); a round
+  // without lists returns at once
+  for (int r = 0; r < reg.rounds; ++r) {
+    if (reg.rounds == 1)
+      hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<1>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
+                         0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u,
+                         counts, desc, entries, grad_loc, grad_aw);
+    else
+      hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<2>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
+                         0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, (uint32_t)r,
+                         counts, desc, entries, grad_loc, grad_aw);
+    if (int rc = check_launch(who)) return rc;
+    uint32_t *work = ctrl + binned::CTRL_WORK + r;
+    if (split)
+      // every tile of this group adds to, or stores into, the zero-filled fp32 tensor
+      hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, float>), dim3(2 * cus), dim3(binned::NT), 0, st,
+                         grad_out, value, shapes, lsi, loc, aw, offs, entries, zero_word, work, ctrl + r,
+                         key_cap, N, S, M, L, P, 1, sums, sums, grad_loc, grad_aw);
+    else
+      hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, GT>), dim3(2 * cus), dim3(binned::NT), 0, st,
+                         grad_out, value, shapes, lsi, loc, aw, offs, entries, zero_word, work, ctrl + r,
+                         key_cap, N, S, M, L, P, 0, grad_value, (float *)nullptr, grad_loc, grad_aw);
+    if (int rc = check_launch(who)) return rc;
+  }
+  if (split && GV16) {
+    hipLaunchKernelGGL(binned::msda_bwd_round_kernel, dim3(2 * cus), dim3(256), 0, st, sums,
+                       reinterpret_cast<bf16_t *>(grad_value), shapes, lsi, N, S, M, L, key_cap,
+                       (uint64_t)(gv_elems / 4));
+    return check_launch(who);
+  }
+  return MSDA_OK;
 }
 
 template <typename VT, typename GT>
@@ -369,7 +442,7 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
   if (g == 0)
     return fail(MSDA_ERR_INVALID_ARGUMENT,
                 "%s: needs a %d-byte aligned device workspace of at least %zu bytes (one image at a time; %zu for the "
-                "whole batch at once, the fastest), got %zu", who, (int)amask + 1, binned_lists_bytes(1, S, M, L, Lq),
+                "whole batch at once, the fastest), got %zu", who, (int)amask + 1, binned_min_bytes(S, M, L, Lq),
                 binned_workspace_bytes(N, S, M, L, Lq, P, GV16), workspace ? workspace_bytes : (size_t)0);
   const size_t pairs_img = (size_t)Lq * M, samples_img = pairs_img * L * P, rows_img = (size_t)S * M * 32;
   for (int n0 = 0; n0 < N; n0 += g) {
@@ -483,12 +556,12 @@ int backward_f32_noalloc(const char *who, const float *value, const int64_t *sha
     return backward_atomic<float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, D, L, Lq, P, grad_value,
                                   grad_loc, grad_aw, static_cast<hipStream_t>(stream));
   // the batch goes through the built-in array in groups of as many images as fit (images are independent)
-  const size_t need = binned_workspace_bytes(1, S, M, L, Lq, P);
+  const size_t need = binned_min_bytes(S, M, L, Lq);
   if (need > NOALLOC_SCRATCH_BYTES)
     return fail(MSDA_ERR_INVALID_ARGUMENT,
-                "%s: one image of this problem needs %zu bytes of sort workspace, more than the %zu-byte built-in "
-                "scratch buffer (about 970,000 (query, head, level) quads per image); use msda_backward_f32_ws with "
-                "a caller-provided workspace", who, need, NOALLOC_SCRATCH_BYTES);
+                "%s: one image of this problem needs at least %zu bytes of sort workspace, more than the %zu-byte "
+                "built-in scratch buffer; use msda_backward_f32_ws with a caller-provided workspace", who, need,
+                NOALLOC_SCRATCH_BYTES);
   void *scratch = nullptr;
   if (int rc = noalloc_scratch(who, &scratch)) return rc;
   return launch_backward_binned<float, float>(who, value, shapes, lsi, loc, aw, grad_out, N, S, M, L, Lq, P,
@@ -664,7 +737,7 @@ int msda_debug_phase_cycles(unsigned long long *out16) {
 }
 #endif
 
-int msda_abi_version(void) { return 4; }
+int msda_abi_version(void) { return 5; }
 
 const char *msda_last_error(void) { return g_err; }
 
@@ -803,13 +876,21 @@ size_t msda_backward_bf16_gv16_workspace_bytes(int batch, int spatial_size, int 
   return binned_workspace_bytes(batch, spatial_size, num_heads, num_levels, num_query, num_point, true);
 }
 
+size_t msda_backward_compact_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
+                                             int num_levels, int num_query, int num_point, int bf16_grad_value) {
+  if (!binned_shape(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point) ||
+      bwd_impl_choice() == 0)
+    return 0;
+  return binned_compact_bytes(batch, spatial_size, num_heads, num_levels, num_query, bf16_grad_value != 0);
+}
+
 size_t msda_backward_min_workspace_bytes(int batch, int spatial_size, int num_heads, int channels,
                                          int num_levels, int num_query, int num_point) {
   if (!binned_shape(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point) ||
       bwd_impl_choice() == 0)
     return 0;
-  // one image at a time, with room for the fp32 staging tensor a bf16 grad_value of one image needs
-  return binned_workspace_bytes(1, spatial_size, num_heads, num_levels, num_query, num_point, true);
+  // one image at a time, one entry per quad (sixteen rounds); anything more is used
+  return binned_min_bytes(spatial_size, num_heads, num_levels, num_query);
 }
 
 int msda_backward_f64(const double *value, const int64_t *spatial_shapes,

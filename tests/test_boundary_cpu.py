@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(lib, s), s
     lib.msda_abi_version.restype = ctypes.c_int
-    assert lib.msda_abi_version() == 4
+    assert lib.msda_abi_version() == 5
     lib.msda_last_error.restype = ctypes.c_char_p
     assert lib.msda_last_error() == b""
 

@@ -1040,16 +1040,19 @@ def test_c_abi_workspace_entry_points(msda):
     torch.cuda.synchronize()
     for got, want in zip((gv, gl, ga), ref):
         assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
-    # a workspace too small for the whole batch: the images go through it in groups (here one at a time), same result
+    # workspaces too small for the whole batch's worst case: the lists go through them in rounds and / or the
+    # images in groups -- one byte short of everything, one image's worth, and the least there is (one image,
+    # one entry per quad: the lists of these model-like locations take two real rounds) -- same results
     small = int(lib.msda_backward_min_workspace_bytes(n, s, m, d, nl, lq, p))
-    assert 0 < small < need
-    rc, gv, gl, ga = call(lib.msda_backward_f32_ws, ws.data_ptr(), need - 1)
-    assert rc == 0, lib.msda_last_error()
-    torch.cuda.synchronize()
-    for got, want in zip((gv, gl, ga), ref):
-        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
     one_image = int(lib.msda_backward_workspace_bytes(1, s, m, d, nl, lq, p))
-    rc, *_ = call(lib.msda_backward_f32_ws, ws.data_ptr(), one_image - 1)
+    assert 0 < small < one_image < need
+    for nbytes in (need - 1, one_image, small):
+        rc, gv, gl, ga = call(lib.msda_backward_f32_ws, ws.data_ptr(), nbytes)
+        assert rc == 0, lib.msda_last_error()
+        torch.cuda.synchronize()
+        for got, want in zip((gv, gl, ga), ref):
+            assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
+    rc, *_ = call(lib.msda_backward_f32_ws, ws.data_ptr(), small - 1)
     assert rc != 0 and b"workspace" in lib.msda_last_error()
     rc, *_ = call(lib.msda_backward_f32_ws, None, 0)
     assert rc != 0 and b"workspace" in lib.msda_last_error()
@@ -1102,6 +1105,117 @@ def test_c_abi_bf16_grad_value_in_bf16_and_in_fp32(msda, oracle, image, batch):
         # run-to-run difference of the fp32 sums themselves, whose order is not fixed)
         diff = (gv16.float() - gv32).abs()
         assert bool((diff <= 2.0 ** -8 * gv32.abs() + 1e-5 * gv32.abs().max()).all())
+
+
+def _corner_locations(shapes, batch, num_query, heads, points, seed):
+    """Sampling locations that put EVERY point on a corner where four 16 x 16 tiles meet, each point of a quad on a
+    different corner where the level has them: a sample's 2 x 2 footprint then lies in four tiles, and a quad is
+    listed once per point and tile -- the most list entries per quad there can be (16 at four points)."""
+    g = torch.Generator().manual_seed(seed)
+    loc = torch.empty((batch, num_query, heads, len(shapes), points, 2))
+    for li, (h, w) in enumerate(shapes):
+        cy, cx = max((h - 1) // 16, 1), max((w - 1) // 16, 1)           # tile corners inside the level
+        ky = torch.randint(1, cy + 1, (batch, num_query, heads, points), generator=g)
+        kx = torch.randint(1, cx + 1, (batch, num_query, heads, points), generator=g)
+        # pixel coordinate 16 k - 0.5 (+ a little): floor = 16 k - 1, the footprint's rows are 16 k - 1 and 16 k
+        loc[:, :, :, li, :, 0] = (16.0 * kx + 0.25) / w
+        loc[:, :, :, li, :, 1] = (16.0 * ky + 0.25) / h
+    return loc
+
+
+@pytest.mark.parametrize("dist", ["uniform", "corners"])
+def test_short_workspaces_take_the_lists_in_rounds(msda, oracle, dist):
+    """msda_backward_f32_ws with entry regions far below the worst case of 16 entries per quad: the lists are
+    written and consumed in several rounds (uniform locations: 4.5 entries per quad; every point on a corner of
+    four tiles: 16, the worst case, which needs every round the host launches).  Against the oracle, with the
+    workspace between sentinels; the bf16-grad_value entry point takes the same path."""
+    from instaorder_amd import synthetic
+    lib, ctypes = _abi()
+    shapes = [(64, 80), (33, 40), (16, 20)]
+    # (seed: one whose locations keep clear of pixel boundaries -- seed 21 has a sample at x = 15 - 5e-7, which fp32
+    # arithmetic, the reference's too, floors to 15 and the fp64 oracle to 14)
+    inp = synthetic.make_inputs(3, shapes, dist="uniform", seed=23, num_query=700)
+    if dist == "corners":
+        inp["sampling_locations"] = _corner_locations(shapes, 3, 700, 8, 4, seed=22)
+    nn = lambda k: inp[k].double().numpy() if inp[k].is_floating_point() else inp[k].numpy()
+    o_gv, o_gl, o_ga = oracle.backward(nn("value"), nn("spatial_shapes"), nn("level_start_index"),
+                                       nn("sampling_locations"), nn("attention_weights"), nn("grad_output"))
+    dev = {k: t.cuda() for k, t in inp.items()}
+    v, go = dev["value"], dev["grad_output"]
+    ss, lsi, loc, aw = dev["spatial_shapes"], dev["level_start_index"], dev["sampling_locations"], dev["attention_weights"]
+    n, s, m, d = v.shape
+    nl, lq, p = ss.shape[0], loc.shape[1], loc.shape[4]
+    dims = (n, s, m, d, nl, lq, p)
+    full = int(lib.msda_backward_workspace_bytes(*dims))
+    least = int(lib.msda_backward_min_workspace_bytes(*dims))
+    quads = n * lq * m * nl
+    # the least; one image with ~3 entries per quad; the batch with ~3 and with ~6 entries per quad
+    sizes = [least, least + 4 * 2 * (quads // n), full - 4 * 13 * quads, full - 4 * 10 * quads]
+    assert all(least <= b < full for b in sizes)
+    guard = 4096
+    stream = torch.cuda.current_stream().cuda_stream
+    for nbytes in sizes:
+        buf = torch.full((guard + nbytes + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+        base = buf.data_ptr() + guard
+        base += (-base) % 16
+        off0 = base - buf.data_ptr()
+        gv, gl, ga = torch.full_like(v, 7.0), torch.full_like(loc, 7.0), torch.full_like(aw, 7.0)
+        rc = lib.msda_backward_f32_ws(v.data_ptr(), ss.data_ptr(), lsi.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                                      go.data_ptr(), *dims, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), base, nbytes,
+                                      stream)
+        assert rc == 0, lib.msda_last_error()
+        torch.cuda.synchronize()
+        assert bool((buf[:off0] == 0x5A).all()) and bool((buf[off0 + nbytes:] == 0x5A).all()), nbytes
+        assert rel_err(gv.cpu().numpy(), o_gv) < GRAD_TOL_F32, nbytes
+        assert rel_err(gl.cpu().numpy(), o_gl) < GRAD_TOL_F32 and rel_err(ga.cpu().numpy(), o_ga) < GRAD_TOL_F32, nbytes
+    # bf16 storage, bf16 grad_value, the least workspace (no room for a staging tensor: unsplit, in rounds)
+    vb, gob = v.bfloat16(), go.bfloat16()
+    r_gv, r_gl, r_ga = msda.ms_deform_attn_backward(vb, ss, lsi, loc, aw, gob, 128)     # whole workspace, one round
+    buf = torch.full((guard + least + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    base = buf.data_ptr() + guard
+    base += (-base) % 16
+    off0 = base - buf.data_ptr()
+    gv, gl, ga = torch.full_like(vb, 7.0), torch.full_like(loc, 7.0), torch.full_like(aw, 7.0)
+    rc = lib.msda_backward_bf16_gv16_ws(vb.data_ptr(), ss.data_ptr(), lsi.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                                        gob.data_ptr(), *dims, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), base, least,
+                                        stream)
+    assert rc == 0, lib.msda_last_error()
+    torch.cuda.synchronize()
+    assert bool((buf[:off0] == 0x5A).all()) and bool((buf[off0 + least:] == 0x5A).all())
+    assert rel_err(gv.float().cpu().numpy(), r_gv.float().cpu().numpy()) < 2.0 ** -7     # two bf16 roundings: one ulp
+    assert rel_err(gl.cpu().numpy(), r_gl.cpu().numpy()) < 1e-4 and rel_err(ga.cpu().numpy(), r_ga.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("image,batch,dtype", [(256, 4, "f32"), (256, 4, "bf16"), (512, 24, "f32"), (512, 24, "bf16")])
+def test_binding_workspace_modes_agree(msda, image, batch, dtype):
+    """ext.workspace_mode: "compact" (msda_backward_compact_workspace_bytes: four entries per quad, four rounds) gives
+    what "full" gives, for small batches (split lists; bf16: the staging tensor behind the compact lists) and for a
+    batch large enough to run unsplit."""
+    from instaorder_amd import ext, synthetic
+    inp = synthetic.make_inputs(batch, synthetic.encoder_shapes(image), dist="model", seed=13, device="cuda")
+    v, go = inp["value"], inp["grad_output"]
+    if dtype == "bf16":
+        v, go = v.bfloat16(), go.bfloat16()
+    args = (v, inp["spatial_shapes"], inp["level_start_index"], inp["sampling_locations"], inp["attention_weights"], go, 128)
+    lib = ext._load()
+    n, s, m, d = v.shape
+    dims = (n, s, m, d, 3, inp["sampling_locations"].shape[1], 4)
+    bf16 = dtype == "bf16"
+    full = int((lib.msda_backward_bf16_gv16_workspace_bytes if bf16 else lib.msda_backward_workspace_bytes)(*dims))
+    compact = int(lib.msda_backward_compact_workspace_bytes(*dims, 1 if bf16 else 0))
+    assert int(lib.msda_backward_min_workspace_bytes(*dims)) < compact < full
+    assert ext.workspace_mode == "full"
+    try:
+        ref = msda.ms_deform_attn_backward(*args)
+        ext.workspace_mode = "compact"
+        got = msda.ms_deform_attn_backward(*args)
+    finally:
+        ext.workspace_mode = "full"
+    assert got[0].dtype == v.dtype
+    # (bf16: two roundings of fp32 sums that agree to ORDER_TOL may land on neighbouring bf16 values: one ulp, <= 2^-7)
+    assert rel_err(got[0].float().cpu().numpy(), ref[0].float().cpu().numpy()) < (2.0 ** -7 if bf16 else ORDER_TOL)
+    for a, b in zip(got[1:], ref[1:]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < ORDER_TOL
 
 
 def test_bf16_grad_value_last_group_smaller_than_the_others(msda, oracle):

@@ -84,9 +84,23 @@ def test_no_alloc_backward_matches_workspace_backward():  # noqa: C901
         assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
     del two, ws, gv0, gl0, ga0, gv, gl, ga
 
-    # a problem whose ONE image exceeds the built-in array is refused, outputs untouched
+    # one image whose worst case (70 MB at 1536^2) exceeds the array: taken with a smaller entry region, in rounds
     lib.msda_backward_min_workspace_bytes.restype = ctypes.c_size_t
-    huge = synthetic.make_inputs(1, synthetic.encoder_shapes(1536), dist="model", seed=35, device="cuda")
+    large = synthetic.make_inputs(1, synthetic.encoder_shapes(1536), dist="model", seed=35, device="cuda")
+    need = int(lib.msda_backward_workspace_bytes(*_dims(large)))
+    assert int(lib.msda_backward_min_workspace_bytes(*_dims(large))) < cap < need
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    rc, gv0, gl0, ga0 = _call(lib, lib.msda_backward_f32_ws, large, ws.data_ptr(), need)
+    assert rc == 0, lib.msda_last_error()
+    rc, gv, gl, ga = _call(lib, lib.msda_backward_f32_noalloc, large)
+    assert rc == 0, lib.msda_last_error()
+    torch.cuda.synchronize()
+    for got, want in ((gv, gv0), (gl, gl0), (ga, ga0)):
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < ORDER_TOL
+    del large, ws, gv0, gl0, ga0, gv, gl, ga
+
+    # a problem whose ONE image cannot run in the array even at one entry per quad is refused, outputs untouched
+    huge = synthetic.make_inputs(1, synthetic.encoder_shapes(3584), dist="uniform", seed=35, device="cuda")
     assert int(lib.msda_backward_min_workspace_bytes(*_dims(huge))) > cap
     rc, gv, gl, ga = _call(lib, lib.msda_backward_f32_noalloc, huge)
     assert rc == 1 and b"built-in scratch" in lib.msda_last_error()
