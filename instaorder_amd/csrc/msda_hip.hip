@@ -302,6 +302,14 @@ size_t binned_compact_bytes(int N, int S, int M, int L, int Lq, bool gv16) {
   if (gv16 && binned_split(N, S, M)) bytes += binned_staging_bytes(N, S, M);
   return bytes;
 }
+// LDS histogram of the binning passes: one word per list of an image.  The host cannot read the level shapes, so it
+// guesses from spatial_size -- levels that are not far from square have about S/256 tiles plus their borders -- and
+// takes the small histogram (8 KB: eight workgroups per CU instead of four; scatter pass 135 -> 124 us at C3) when
+// twice that fits; a wrong guess costs speed, not results (the kernels fall back to counting in global memory).
+uint32_t binned_kcap(int S, int M, int L) {
+  const size_t guess = (size_t)M * (2 * (size_t)((S + binned::TP - 1) / binned::TP) + 8 * (size_t)L);
+  return guess <= (size_t)binned::KCAP_SMALL ? binned::KCAP_SMALL : binned::KCAP;
+}
 // the least a group of ONE image can run in: one entry per quad plus the longest list there can be (a list holds
 // at most one entry per point of each of the image's queries) -- sixteen rounds
 size_t binned_min_bytes(int S, int M, int L, int Lq) {
@@ -380,9 +388,10 @@ int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
   if (int rc = check_launch(who)) return rc;
   const uint64_t magic_ml = (((uint64_t)1 << 40) + (uint64_t)(M * L) - 1) / (uint64_t)(M * L);
   const uint64_t magic_l = (((uint64_t)1 << 40) + (uint64_t)L - 1) / (uint64_t)L;
+  const uint32_t kcap = binned_kcap(S, M, L);
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<0>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                     0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u, counts, desc,
-                     entries, grad_loc, grad_aw);
+                     kcap * 4, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u, kcap,
+                     counts, desc, entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, lsi, N, S, M, L,
                      key_cap, (uint32_t)reg.e_cap, reg.rounds, counts, offs);
@@ -401,12 +410,12 @@ int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
   for (int r = 0; r < reg.rounds; ++r) {
     if (reg.rounds == 1)
       hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<1>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                         0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u,
-                         counts, desc, entries, grad_loc, grad_aw);
+                         kcap * 4, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u,
+                         kcap, counts, desc, entries, grad_loc, grad_aw);
     else
       hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<2>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
-                         0, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, (uint32_t)r,
-                         counts, desc, entries, grad_loc, grad_aw);
+                         kcap * 4, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap,
+                         (uint32_t)r, kcap, counts, desc, entries, grad_loc, grad_aw);
     if (int rc = check_launch(who)) return rc;
     uint32_t *work = ctrl + binned::CTRL_WORK + r;
     if (split)

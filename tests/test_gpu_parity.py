@@ -955,6 +955,9 @@ def _off_lattice(inp):
     ([(33, 17)], 2, 3, 1, "uniform"),                          # a single query
     ([(64, 64), (32, 32), (16, 16)], 8, 4, None, "model"),     # fine level first (queue order)
     ([(1, 200), (200, 1)], 4, 2, 50, "uniform"),               # strips: one tile per 16 pixels
+    ([(1, 160)] * 8, 26, 4, 100, "uniform"),                   # 2080 lists per image where the host's guess from
+                                                               # spatial_size expects 1924: the binning passes count in
+                                                               # global memory instead of their (small) LDS histogram
 ])
 def test_binned_backward_shapes_vs_oracle(msda, oracle, shapes, heads, points, num_query, dist):
     from instaorder_amd import synthetic
