@@ -219,7 +219,9 @@ int msda_backward_bf16_gv16_ws(const uint16_t *value, const int64_t *spatial_sha
  * Forward: channels == 32 and num_levels * num_point <= 16, else MSDA_ERR_INVALID_ARGUMENT (fall
  * back to the unfused entry points).  Backward: any shape msda_backward_f32 takes; the workspace
  * (256-byte aligned, msda_fused_backward_workspace_bytes(...) bytes) holds the recomputed
- * locations and weights plus the sort-by-tile lists.  No gradient for reference_points is
+ * locations and weights, the sort-by-tile lists and (channels == 32) the location / weight
+ * gradients in the kernels' own [M, L, N*Lq, P] order, which the epilogue pass turns into the
+ * caller's -- 36 bytes per sample plus the lists in all.  No gradient for reference_points is
  * returned (it is sum over heads and points of grad_sampling_offsets * (W_l, H_l)).
  */
 int msda_fused_forward_f32(const float *value, const int64_t *spatial_shapes,

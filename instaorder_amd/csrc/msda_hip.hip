@@ -354,7 +354,7 @@ int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
                         const int64_t *lsi, const float *loc, const float *aw,
                         const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
                         GT *grad_value, float *grad_loc, float *grad_aw, void *workspace, size_t workspace_bytes,
-                        hipStream_t st) {
+                        hipStream_t st, bool planar = false) {
   constexpr bool GV16 = sizeof(GT) == 2;
   // Small batches split their long lists over workgroups that add into a zero-filled fp32 tensor: grad_value
   // itself, or (bf16 grad_value) a staging tensor at the END of the workspace -- when there is room for it without
@@ -389,9 +389,11 @@ int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
   const uint64_t magic_ml = (((uint64_t)1 << 40) + (uint64_t)(M * L) - 1) / (uint64_t)(M * L);
   const uint64_t magic_l = (((uint64_t)1 << 40) + (uint64_t)L - 1) / (uint64_t)L;
   const uint32_t kcap = binned_kcap(S, M, L);
+  // the fused boundary: grad_loc / grad_aw in the scratch layout [M, L, N * Lq, P] (binned.inc, PLANAR)
+  const uint32_t planar_nq = planar ? (uint32_t)((size_t)N * Lq) : 0u;
   hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<0>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
                      kcap * 4, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u, kcap,
-                     counts, desc, entries, grad_loc, grad_aw);
+                     planar_nq, counts, desc, entries, grad_loc, grad_aw);
   if (int rc = check_launch(who)) return rc;
   hipLaunchKernelGGL(binned::msda_bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, shapes, lsi, N, S, M, L,
                      key_cap, (uint32_t)reg.e_cap, reg.rounds, counts, offs);
@@ -411,22 +413,32 @@ int launch_binned_group(const char *who, const VT *value, const int64_t *shapes,
     if (reg.rounds == 1)
       hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<1>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
                          kcap * 4, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap, 0u,
-                         kcap, counts, desc, entries, grad_loc, grad_aw);
+                         kcap, planar_nq, counts, desc, entries, grad_loc, grad_aw);
     else
       hipLaunchKernelGGL(binned::msda_bwd_bin_kernel<2>, dim3((uint32_t)N * bpi), dim3(binned::BIN_NT),
                          kcap * 4, st, shapes, lsi, loc, N, S, M, L, Lq, P, spi, bpi, magic_ml, magic_l, key_cap,
-                         (uint32_t)r, kcap, counts, desc, entries, grad_loc, grad_aw);
+                         (uint32_t)r, kcap, planar_nq, counts, desc, entries, grad_loc, grad_aw);
     if (int rc = check_launch(who)) return rc;
     uint32_t *work = ctrl + binned::CTRL_WORK + r;
+    if constexpr (!GV16) {
+      if (planar) {                                      // (fp32 grad_value only: the fused boundary's)
+        hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, float, true>), dim3(2 * cus), dim3(binned::NT), 0, st,
+                           grad_out, value, shapes, lsi, loc, aw, offs, entries, zero_word, work, ctrl + r,
+                           key_cap, N, S, M, L, P, split ? 1 : 0, planar_nq, reinterpret_cast<float *>(grad_value),
+                           split ? sums : (float *)nullptr, grad_loc, grad_aw);
+        if (int rc = check_launch(who)) return rc;
+        continue;
+      }
+    }
     if (split)
       // every tile of this group adds to, or stores into, the zero-filled fp32 tensor
       hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, float>), dim3(2 * cus), dim3(binned::NT), 0, st,
                          grad_out, value, shapes, lsi, loc, aw, offs, entries, zero_word, work, ctrl + r,
-                         key_cap, N, S, M, L, P, 1, sums, sums, grad_loc, grad_aw);
+                         key_cap, N, S, M, L, P, 1, 0u, sums, sums, grad_loc, grad_aw);
     else
       hipLaunchKernelGGL((binned::msda_bwd_binned_kernel<VT, GT>), dim3(2 * cus), dim3(binned::NT), 0, st,
                          grad_out, value, shapes, lsi, loc, aw, offs, entries, zero_word, work, ctrl + r,
-                         key_cap, N, S, M, L, P, 0, grad_value, (float *)nullptr, grad_loc, grad_aw);
+                         key_cap, N, S, M, L, P, 0, 0u, grad_value, (float *)nullptr, grad_loc, grad_aw);
     if (int rc = check_launch(who)) return rc;
   }
   if (split && GV16) {
@@ -443,7 +455,7 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
                            const int64_t *lsi, const float *loc, const float *aw,
                            const VT *grad_out, int N, int S, int M, int L, int Lq, int P,
                            GT *grad_value, float *grad_loc, float *grad_aw, void *workspace,
-                           size_t workspace_bytes, hipStream_t st) {
+                           size_t workspace_bytes, hipStream_t st, bool planar = false) {
   constexpr bool GV16 = sizeof(GT) == 2;
   const uintptr_t amask = GV16 ? 15u : 3u;             // bf16 grad_value: an fp32 staging tensor may sit behind the lists
   const int g = (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & amask))
@@ -453,13 +465,15 @@ int launch_backward_binned(const char *who, const VT *value, const int64_t *shap
                 "%s: needs a %d-byte aligned device workspace of at least %zu bytes (one image at a time; %zu for the "
                 "whole batch at once, the fastest), got %zu", who, (int)amask + 1, binned_min_bytes(S, M, L, Lq),
                 binned_workspace_bytes(N, S, M, L, Lq, P, GV16), workspace ? workspace_bytes : (size_t)0);
+  if (planar && g != N)      // the scratch layout spans the batch; the fused boundary brings the whole batch's workspace
+    return fail(MSDA_ERR_INVALID_ARGUMENT, "%s: the fused backward needs the workspace of the whole batch", who);
   const size_t pairs_img = (size_t)Lq * M, samples_img = pairs_img * L * P, rows_img = (size_t)S * M * 32;
   for (int n0 = 0; n0 < N; n0 += g) {
     const int ng = N - n0 < g ? N - n0 : g;
     if (int rc = launch_binned_group<VT, GT>(who, value + n0 * rows_img, shapes, lsi, loc + n0 * samples_img * 2,
                                              aw + n0 * samples_img, grad_out + n0 * pairs_img * 32, ng, S, M, L,
                                              Lq, P, grad_value + n0 * rows_img, grad_loc + n0 * samples_img * 2,
-                                             grad_aw + n0 * samples_img, workspace, workspace_bytes, st))
+                                             grad_aw + n0 * samples_img, workspace, workspace_bytes, st, planar))
       return rc;
   }
   return MSDA_OK;
@@ -635,7 +649,9 @@ size_t fused_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq,
   size_t inner = 0;
   if (binned_shape(N, S, M, D, L, Lq, P) && bwd_impl_choice() != 0)
     inner = binned_workspace_bytes(N, S, M, L, Lq, P);
-  return align256(samples * 8) + align256(samples * 4) + align256(inner);
+  // + the backward's own layout of grad_loc / grad_aw (binned.inc, PLANAR), which the epilogue kernel reads back
+  const size_t scratch = inner ? align256(samples * 8) + align256(samples * 4) : 0;
+  return align256(samples * 8) + align256(samples * 4) + scratch + align256(inner);
 }
 
 // `value` / `grad_out` are fp32 or (bf16 == true) bfloat16 bit patterns
@@ -653,8 +669,18 @@ int fused_backward(const char *who, bool bf16, const void *value, const int64_t 
   const size_t npairs = (size_t)N * Lq * M, samples = npairs * L * P;
   float *loc = static_cast<float *>(workspace);
   float *aw = reinterpret_cast<float *>(static_cast<char *>(workspace) + align256(samples * 8));
-  void *inner = static_cast<char *>(workspace) + align256(samples * 8) + align256(samples * 4);
-  const size_t inner_bytes = need - align256(samples * 8) - align256(samples * 4);
+  char *rest = static_cast<char *>(workspace) + align256(samples * 8) + align256(samples * 4);
+  // The binned kernels leave grad_loc / grad_aw in their own layout, in scratch, and the epilogue reads them from
+  // there: an item of the tile kernel is one (level, head), and in the caller's [N, Lq, M, L, P] order its results
+  // are 16 bytes out of every 384 -- 0.4 ms of partial-line write-backs at bs 32 / 1024^2 (experiments README, 7).
+  const bool planar = binned_shape(N, S, M, D, L, Lq, P) && bwd_impl_choice() != 0 &&
+                      (bf16 ? (reinterpret_cast<uintptr_t>(value) & 7u) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 7u) == 0
+                            : aligned16(value) && aligned16(grad_out)) && aligned16(grad_value);
+  float *gl_scratch = reinterpret_cast<float *>(rest), *ga_scratch = reinterpret_cast<float *>(rest + align256(samples * 8));
+  const size_t scratch_bytes = binned_shape(N, S, M, D, L, Lq, P) && bwd_impl_choice() != 0
+                                   ? align256(samples * 8) + align256(samples * 4) : 0;
+  void *inner = rest + scratch_bytes;
+  const size_t inner_bytes = need - align256(samples * 8) - align256(samples * 4) - scratch_bytes;
   const size_t nblk = (npairs + FUSED_PB - 1) / FUSED_PB;
   if (nblk > 0x7fffffffull) return fail(MSDA_ERR_INVALID_ARGUMENT, "%s: problem too large", who);
   if (L * P > FUSED_MAX_LP)
@@ -664,17 +690,32 @@ int fused_backward(const char *who, bool bf16, const void *value, const int64_t 
                        logits, M, L, P, npairs, loc, aw);
     if (int rc = check_launch(who)) return rc;
   }
-  const int rc = bf16 ? backward_bf16(who, static_cast<const uint16_t *>(value), shapes, lsi, loc, aw,
-                                      static_cast<const uint16_t *>(grad_out), N, S, M, D, L, Lq, P, grad_value, false,
-                                      grad_off, grad_logits, inner, inner_bytes, false, stream)
-                      : backward_f32(who, static_cast<const float *>(value), shapes, lsi, loc, aw,
-                                     static_cast<const float *>(grad_out), N, S, M, D, L, Lq, P, grad_value,
-                                     grad_off, grad_logits, inner, inner_bytes, false, stream);
+  int rc;
+  if (planar)
+    rc = bf16 ? launch_backward_binned<bf16_t, float>(who, static_cast<const bf16_t *>(value), shapes, lsi, loc, aw,
+                                                      static_cast<const bf16_t *>(grad_out), N, S, M, L, Lq, P,
+                                                      grad_value, gl_scratch, ga_scratch, inner, inner_bytes, st, true)
+              : launch_backward_binned<float, float>(who, static_cast<const float *>(value), shapes, lsi, loc, aw,
+                                                     static_cast<const float *>(grad_out), N, S, M, L, Lq, P,
+                                                     grad_value, gl_scratch, ga_scratch, inner, inner_bytes, st, true);
+  else
+    rc = bf16 ? backward_bf16(who, static_cast<const uint16_t *>(value), shapes, lsi, loc, aw,
+                              static_cast<const uint16_t *>(grad_out), N, S, M, D, L, Lq, P, grad_value, false,
+                              grad_off, grad_logits, inner, inner_bytes, false, stream)
+              : backward_f32(who, static_cast<const float *>(value), shapes, lsi, loc, aw,
+                             static_cast<const float *>(grad_out), N, S, M, D, L, Lq, P, grad_value,
+                             grad_off, grad_logits, inner, inner_bytes, false, stream);
   if (rc) return rc;
-  if (npairs) {
+  if (npairs && planar) {
+    const uint32_t NQ = (uint32_t)((size_t)N * Lq), qb = (uint32_t)(FUSED_PB / M > 0 ? FUSED_PB / M : 1);
+    const size_t lds = (size_t)qb * M * L * P * 3 * sizeof(float);
+    hipLaunchKernelGGL(msda_fused_epilogue_planar_kernel, dim3((NQ + qb - 1) / qb), dim3(256), lds, st, shapes, aw, M, L,
+                       P, NQ, qb, gl_scratch, ga_scratch, grad_off, grad_logits);
+    if (int rc2 = check_launch(who)) return rc2;
+  } else if (npairs) {
     hipLaunchKernelGGL(msda_fused_epilogue_kernel, dim3((unsigned)nblk), dim3(256), 0, st, shapes, aw, L, P,
                        npairs, grad_off, grad_logits);
-    if (int rc = check_launch(who)) return rc;
+    if (int rc2 = check_launch(who)) return rc2;
   }
   return MSDA_OK;
 }
