@@ -673,7 +673,7 @@ int fused_backward(const char *who, bool bf16, const void *value, const int64_t 
   // The binned kernels leave grad_loc / grad_aw in their own layout, in scratch, and the epilogue reads them from
   // there: an item of the tile kernel is one (level, head), and in the caller's [N, Lq, M, L, P] order its results
   // are 16 bytes out of every 384 -- 0.4 ms of partial-line write-backs at bs 32 / 1024^2 (experiments README, 7).
-  const bool planar = binned_shape(N, S, M, D, L, Lq, P) && bwd_impl_choice() != 0 &&
+  const bool planar = binned_shape(N, S, M, D, L, Lq, P) && bwd_impl_choice() != 0 && M <= FUSED_PB &&   // (the epilogue takes all heads of a query in one workgroup)
                       (bf16 ? (reinterpret_cast<uintptr_t>(value) & 7u) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 7u) == 0
                             : aligned16(value) && aligned16(grad_out)) && aligned16(grad_value);
   float *gl_scratch = reinterpret_cast<float *>(rest), *ga_scratch = reinterpret_cast<float *>(rest + align256(samples * 8));

@@ -1339,6 +1339,8 @@ def test_fused_entry_points_match_unfused(msda, shapes, heads, points, num_query
     ([(13, 7)], 1, 1, 1, 1),                                      # one level, one point, one head, one query
     ([(4, 4), (5, 5), (6, 6), (7, 7), (8, 8), (3, 9), (9, 3), (2, 2)], 4, 2, 40, 2),      # 8 levels
     ([(4, 4), (5, 5), (6, 6), (7, 7), (8, 8), (3, 9), (9, 3), (2, 2), (10, 4)], 2, 1, 33, 2),   # 9 levels: generic backward inside
+    ([(6, 7), (3, 4)], 66, 2, 9, 1),                              # more heads than the epilogue's workgroup takes: gradients in the caller's layout
+    ([(20, 24), (10, 12)], 5, 4, 70, 2),                          # five heads: the epilogue's general indexing
 ])
 def test_fused_entry_points_vs_oracle(msda, oracle, shapes, heads, points, num_query, batch):
     """The fused entry points against the C ORACLE (not against the unfused HIP path): softmax and
