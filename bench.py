@@ -172,8 +172,33 @@ class Workload:
         return fwd_gbs, bwd_gbs, both_gbs
 
 
-def short_run(torch, MSDA, synthetic, name, dtype, steps=10, warmup=3):
-    w = Workload(torch, MSDA, synthetic, name, "model", dtype, seed=0)
+class FusedWorkload(Workload):
+    """The same workload through the opt-in fused boundary: the op plus the softmax
+    and the sampling-location arithmetic of its caller, from the raw offsets and logits."""
+
+    def __init__(self, torch, MSDA, synthetic, name, dist, dtype, seed):
+        super().__init__(torch, MSDA, synthetic, name, dist, dtype, seed)
+        from instaorder_amd import ext
+        self.ext = ext
+        n, lq, m, nl, p, _ = self.loc.shape
+        self.ref = synthetic.reference_points(self.shapes).to(self.loc.device)[None, :, None, :].expand(n, lq, nl, 2).contiguous()
+        wh = torch.tensor([(w, h) for h, w in self.shapes], dtype=torch.float32, device=self.loc.device)
+        self.off = ((self.loc - self.ref[:, :, None, :, None, :]) * wh[None, None, None, :, None, :]).contiguous()
+        self.logits = torch.log(self.aw.clamp_min(1e-20)).reshape(n, lq, m, nl * p).contiguous()
+        del self.loc, self.aw
+
+    def forward(self):
+        return self.ext.ms_deform_attn_fused_forward(self.v, self.ss, self.lsi, self.ref, self.off, self.logits)
+
+    def backward(self):
+        return self.ext.ms_deform_attn_fused_backward(self.v, self.ss, self.lsi, self.ref, self.off, self.logits, self.go)
+
+    def describe(self):
+        return super().describe() + "; FUSED boundary (row f3, opt-in): softmax and location arithmetic of the caller inside the calls"
+
+
+def short_run(torch, MSDA, synthetic, name, dtype, steps=10, warmup=3, fused=False):
+    w = (FusedWorkload if fused else Workload)(torch, MSDA, synthetic, name, "model", dtype, seed=0)
     for _ in range(warmup):
         w.step()
     torch.cuda.synchronize()
@@ -303,6 +328,11 @@ def main():
             if (name, dtype) != (args.workload, args.dtype):
                 extras.append(short_run(torch, MSDA, synthetic, name, dtype))
                 torch.cuda.empty_cache()
+        try:      # the opt-in fused boundary at the headline shape; never at the expense of the line itself
+            extras.append(short_run(torch, MSDA, synthetic, args.workload, args.dtype, fused=True))
+        except Exception as e:  # noqa: BLE001
+            extras.append({"workload": "fused boundary", "error": str(e)[:200]})
+        torch.cuda.empty_cache()
         result["detail"]["other_workloads"] = extras
     if not args.no_cpu_baseline and world == 1:
         shapes = synthetic.encoder_shapes(WORKLOADS[args.workload][1])
